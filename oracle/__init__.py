@@ -1,0 +1,370 @@
+"""ctypes front-end of the CPU ORACLE (oracle/tfhe_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: may be imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (fhe-string-bounty_amd/) never imports this module.
+
+The C file restates the tfhe-rs 0.5.0 hot path of the reference (citations inside); this wrapper
+only marshals numpy arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force: bool = False, arch: str | None = None) -> str:
+    """Compile liboracle.so with gcc (no-op when it is already there)."""
+    if force or not os.path.exists(_LIB_PATH):
+        cmd = ["make", "-C", _HERE, "-B" if force else "-s"]
+        if arch:
+            cmd.append(f"ARCH={arch}")
+        subprocess.check_call(cmd)
+    return _LIB_PATH
+
+
+class _Params(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32), ("k", C.c_uint32), ("N", C.c_uint32),
+        ("pbs_base_log", C.c_uint32), ("pbs_level", C.c_uint32),
+        ("ks_base_log", C.c_uint32), ("ks_level", C.c_uint32),
+        ("msg_mod", C.c_uint32), ("carry_mod", C.c_uint32),
+        ("lwe_std", C.c_double), ("glwe_std", C.c_double),
+    ]
+
+
+@dataclass(frozen=True)
+class Params:
+    """shortint ClassicPBSParameters (reference: shortint/parameters/mod.rs:61-76)."""
+    n: int
+    k: int
+    N: int
+    pbs_base_log: int
+    pbs_level: int
+    ks_base_log: int
+    ks_level: int
+    msg_mod: int
+    carry_mod: int
+    lwe_std: float
+    glwe_std: float
+    name: str = ""
+
+    @property
+    def big_dim(self) -> int:
+        return self.k * self.N
+
+    @property
+    def big_size(self) -> int:
+        return self.k * self.N + 1
+
+    @property
+    def small_size(self) -> int:
+        return self.n + 1
+
+    @property
+    def glwe_len(self) -> int:
+        return (self.k + 1) * self.N
+
+    @property
+    def delta(self) -> int:
+        return (1 << 63) // (self.msg_mod * self.carry_mod)
+
+    def c(self) -> _Params:
+        return _Params(self.n, self.k, self.N, self.pbs_base_log, self.pbs_level, self.ks_base_log,
+                       self.ks_level, self.msg_mod, self.carry_mod, self.lwe_std, self.glwe_std)
+
+
+# reference: shortint/parameters/mod.rs:703-717, :658-672, :613-627, :1063-1077
+PARAM_MESSAGE_2_CARRY_2_KS_PBS = Params(742, 1, 2048, 23, 1, 3, 5, 4, 4,
+                                        0.000007069849454709433, 0.00000000000000029403601535432533,
+                                        "PARAM_MESSAGE_2_CARRY_2_KS_PBS")
+PARAM_MESSAGE_2_CARRY_1_KS_PBS = Params(742, 2, 1024, 23, 1, 4, 3, 4, 2,
+                                        0.000007069849454709433, 0.00000000000000029403601535432533,
+                                        "PARAM_MESSAGE_2_CARRY_1_KS_PBS")
+PARAM_MESSAGE_1_CARRY_1_KS_PBS = Params(684, 3, 512, 18, 1, 4, 3, 2, 2,
+                                        0.00002043784477291318, 0.0000000000034525330484572114,
+                                        "PARAM_MESSAGE_1_CARRY_1_KS_PBS")
+PARAM_MESSAGE_4_CARRY_4_KS_PBS = Params(996, 1, 32768, 15, 2, 3, 7, 16, 16,
+                                        0.00000006767666038309478, 0.0000000000000000002168404344971009,
+                                        "PARAM_MESSAGE_4_CARRY_4_KS_PBS")
+# Tiny sets for fast tests (NOT secure; noise small enough that decryption is always right).
+TOY_K1 = Params(16, 1, 256, 10, 2, 4, 4, 4, 4, 1e-12, 1e-15, "TOY_K1_N256_L2")
+TOY_K2 = Params(12, 2, 128, 12, 1, 3, 5, 2, 2, 1e-12, 1e-15, "TOY_K2_N128_L1")
+
+_u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    P = C.POINTER(_Params)
+    u64, u32, sz, dbl, vp, i32 = C.c_uint64, C.c_uint32, C.c_size_t, C.c_double, C.c_void_p, C.c_int
+
+    def sig(name, res, *args):
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = list(args)
+
+    sig("orc_closest_representable", u64, u64, u32, u32, u32)
+    sig("orc_decompose", None, u64, u32, u32, u32, _u64p)
+    sig("orc_modulus_switch", u64, u64, u32)
+    sig("orc_monomial_div", None, _u64p, _u64p, u32, u64, u32)
+    sig("orc_monomial_mul", None, _u64p, _u64p, u32, u64, u32)
+    sig("orc_monomial_mul_and_subtract", None, _u64p, _u64p, u32, u64, u32)
+    sig("orc_slice_sub_scalar_mul", None, _u64p, _u64p, u64, sz, u32)
+    sig("orc_from_torus", u64, dbl)
+    sig("orc_f64_to_i64", C.c_int64, dbl)
+    sig("orc_keyswitch", None, P, _u64p, _u64p, _u64p)
+    sig("orc_sample_extract", None, P, _u64p, _u64p)
+    sig("orc_fft_new", vp, u32)
+    sig("orc_fft_free", None, vp)
+    sig("orc_fft_forward_as_integer", None, vp, _f64p, _u64p)
+    sig("orc_fft_forward_as_torus", None, vp, _f64p, _u64p)
+    sig("orc_fft_add_backward_as_torus", None, vp, _u64p, _f64p)
+    sig("orc_bsk_to_fourier", None, P, _u64p, _f64p)
+    sig("orc_add_external_product_fft", None, P, vp, _u64p, _f64p, _u64p)
+    sig("orc_add_external_product_exact", None, P, _u64p, _u64p, _u64p)
+    sig("orc_blind_rotate_fft", None, P, vp, _f64p, _u64p, _u64p)
+    sig("orc_blind_rotate_exact", None, P, _u64p, _u64p, _u64p)
+    sig("orc_pbs_fft", None, P, vp, _f64p, _u64p, _u64p, _u64p)
+    sig("orc_pbs_exact", None, P, _u64p, _u64p, _u64p, _u64p)
+    sig("orc_ks_pbs_batch", None, P, _u64p, vp, vp, i32, _u64p, vp, _u64p, _u64p, sz, i32)
+    sig("orc_fill_accumulator", u64, P, _u64p, _u64p)
+    sig("orc_trivial_pbs_body", u64, P, u64, _u64p)
+    sig("orc_gen_binary_key", None, u64, u64, _u64p, sz)
+    sig("orc_lwe_encrypt", None, _u64p, sz, u64, dbl, vp, _u64p)
+    sig("orc_lwe_decrypt", u64, _u64p, sz, _u64p)
+    sig("orc_gen_ksk", None, P, _u64p, _u64p, u64, _u64p)
+    sig("orc_gen_bsk", None, P, _u64p, _u64p, u64, _u64p, i32)
+    sig("orc_encode", u64, P, u64)
+    sig("orc_decode", u64, P, u64)
+    sig("orc_rng_init", None, vp, u64, u64)
+    sig("orc_rng_next", u64, vp)
+    _lib = L
+    return L
+
+
+def _a(x, dtype=np.uint64):
+    return np.ascontiguousarray(x, dtype=dtype)
+
+
+# --------------------------------------------------------------------- integer helpers
+def closest_representable(x, base_log, level, bits=64):
+    return int(lib().orc_closest_representable(int(x), base_log, level, bits))
+
+
+def decompose(x, base_log, level, bits=64):
+    out = np.zeros(level, dtype=np.uint64)
+    lib().orc_decompose(int(x), base_log, level, bits, out)
+    return out
+
+
+def modulus_switch(x, log2N):
+    return int(lib().orc_modulus_switch(int(x), log2N))
+
+
+def monomial_div(poly, degree, bits=64):
+    poly = _a(poly)
+    out = np.zeros_like(poly)
+    lib().orc_monomial_div(out, poly, len(poly), degree, bits)
+    return out
+
+
+def monomial_mul(poly, degree, bits=64):
+    poly = _a(poly)
+    out = np.zeros_like(poly)
+    lib().orc_monomial_mul(out, poly, len(poly), degree, bits)
+    return out
+
+
+def monomial_mul_and_subtract(poly, degree, bits=64):
+    poly = _a(poly)
+    out = np.zeros_like(poly)
+    lib().orc_monomial_mul_and_subtract(out, poly, len(poly), degree, bits)
+    return out
+
+
+def slice_sub_scalar_mul(out, inp, scalar, bits=64):
+    out = _a(out).copy()
+    lib().orc_slice_sub_scalar_mul(out, _a(inp), int(scalar), len(out), bits)
+    return out
+
+
+def from_torus(x: float) -> int:
+    return int(lib().orc_from_torus(float(x)))
+
+
+def f64_to_i64(x: float) -> int:
+    return int(lib().orc_f64_to_i64(float(x)))
+
+
+# --------------------------------------------------------------------- client side (harness)
+class Rng:
+    def __init__(self, seed: int, stream: int = 0):
+        self.buf = (C.c_uint64 * 4)()
+        lib().orc_rng_init(C.addressof(self.buf), seed, stream)
+
+    def next(self) -> int:
+        return int(lib().orc_rng_next(C.addressof(self.buf)))
+
+    @property
+    def ptr(self):
+        return C.addressof(self.buf)
+
+
+class ClientKey:
+    """Secret keys of one parameter set, generated from a seed (binary keys).
+
+    reference: shortint/engine/client_side.rs:13-56 (big LWE key == flattened GLWE key)."""
+
+    def __init__(self, params: Params, seed: int):
+        self.params = params
+        self.seed = seed
+        self.glwe_sk = np.zeros(params.k * params.N, dtype=np.uint64)
+        self.small_sk = np.zeros(params.n, dtype=np.uint64)
+        lib().orc_gen_binary_key(seed, 1, self.glwe_sk, self.glwe_sk.size)
+        lib().orc_gen_binary_key(seed, 2, self.small_sk, self.small_sk.size)
+        self.big_sk = self.glwe_sk  # client_side.rs:29
+        self._rng = Rng(seed, 3)
+
+    def encrypt_plaintext(self, pt: int, rng: Rng | None = None) -> np.ndarray:
+        p = self.params
+        ct = np.zeros(p.big_size, dtype=np.uint64)
+        lib().orc_lwe_encrypt(self.big_sk, p.big_dim, int(pt) & (2**64 - 1), p.glwe_std,
+                              (rng or self._rng).ptr, ct)
+        return ct
+
+    def encrypt(self, msg: int, rng: Rng | None = None) -> np.ndarray:
+        """message + carry space encryption (client_side.rs:58-86 with m < msg*carry)."""
+        return self.encrypt_plaintext(int(lib().orc_encode(C.byref(self.params.c()), int(msg))), rng)
+
+    def encrypt_many(self, msgs, rng: Rng | None = None) -> np.ndarray:
+        return np.stack([self.encrypt(int(m), rng) for m in msgs])
+
+    def decrypt_plaintext(self, ct) -> int:
+        return int(lib().orc_lwe_decrypt(self.big_sk, self.params.big_dim, _a(ct)))
+
+    def decrypt_small_plaintext(self, ct) -> int:
+        return int(lib().orc_lwe_decrypt(self.small_sk, self.params.n, _a(ct)))
+
+    def decrypt_message_and_carry(self, ct) -> int:
+        return int(lib().orc_decode(C.byref(self.params.c()), self.decrypt_plaintext(ct)))
+
+    def decrypt(self, ct) -> int:
+        return self.decrypt_message_and_carry(ct) % self.params.msg_mod
+
+    def decrypt_many(self, cts) -> np.ndarray:
+        return np.array([self.decrypt_message_and_carry(c) for c in cts], dtype=np.int64)
+
+
+class ServerKey:
+    """Oracle twin of shortint::ServerKey: KSK + standard BSK + Fourier BSK + the operators."""
+
+    def __init__(self, ck: ClientKey, threads: int | None = None, fourier: bool = True):
+        p = ck.params
+        self.params = p
+        self.threads = threads or min(8, os.cpu_count() or 1)
+        pc = p.c()
+        self.ksk = np.zeros(p.big_dim * p.ks_level * p.small_size, dtype=np.uint64)
+        lib().orc_gen_ksk(C.byref(pc), ck.big_sk, ck.small_sk, ck.seed, self.ksk)
+        self.bsk = np.zeros(p.n * p.pbs_level * (p.k + 1) ** 2 * p.N, dtype=np.uint64)
+        lib().orc_gen_bsk(C.byref(pc), ck.small_sk, ck.glwe_sk, ck.seed, self.bsk, self.threads)
+        self.fbsk = None
+        if fourier:
+            self.fbsk = np.zeros(self.bsk.size, dtype=np.float64)
+            lib().orc_bsk_to_fourier(C.byref(pc), self.bsk, self.fbsk)
+
+    # shortint/server_key/mod.rs:383-399
+    def generate_lookup_table(self, f):
+        p = self.params
+        table = np.array([int(f(i)) for i in range(p.msg_mod * p.carry_mod)], dtype=np.uint64)
+        lut = np.zeros(p.glwe_len, dtype=np.uint64)
+        degree = int(lib().orc_fill_accumulator(C.byref(p.c()), table, lut))
+        return lut, degree
+
+    # shortint/server_key/bivariate_pbs.rs:71-96,125-130
+    def generate_lookup_table_bivariate(self, f, factor=None):
+        p = self.params
+        factor = factor or p.msg_mod
+        return self.generate_lookup_table(
+            lambda x: f((x // factor) % p.msg_mod, (x % factor) % p.msg_mod))
+
+    def keyswitch(self, ct_big):
+        p = self.params
+        out = np.zeros(p.small_size, dtype=np.uint64)
+        lib().orc_keyswitch(C.byref(p.c()), self.ksk, _a(ct_big), out)
+        return out
+
+    def pbs(self, ct_small, lut, exact=False):
+        p = self.params
+        out = np.zeros(p.big_size, dtype=np.uint64)
+        if exact:
+            lib().orc_pbs_exact(C.byref(p.c()), self.bsk, _a(ct_small), _a(lut), out)
+        else:
+            f = lib().orc_fft_new(p.N)
+            lib().orc_pbs_fft(C.byref(p.c()), f, self.fbsk, _a(ct_small), _a(lut), out)
+            lib().orc_fft_free(f)
+        return out
+
+    def apply_lookup_table_batch(self, cts, luts, lut_idx=None, exact=False, threads=None):
+        """KS -> PBS for every row of `cts` (shortint/server_key/mod.rs:783-857)."""
+        p = self.params
+        cts = _a(cts).reshape(-1, p.big_size)
+        luts = _a(luts).reshape(-1, p.glwe_len)
+        out = np.zeros_like(cts)
+        idx = None
+        if lut_idx is not None:
+            idx_arr = _a(lut_idx, np.uint32)
+            assert idx_arr.size == cts.shape[0] and int(idx_arr.max(initial=0)) < luts.shape[0]
+            idx = idx_arr.ctypes.data_as(C.c_void_p)
+        fb = self.fbsk.ctypes.data_as(C.c_void_p) if self.fbsk is not None else None
+        lib().orc_ks_pbs_batch(C.byref(p.c()), self.ksk, fb, self.bsk.ctypes.data_as(C.c_void_p),
+                               1 if exact else 0, cts, idx, luts, out, cts.shape[0],
+                               threads or self.threads)
+        return out
+
+    def apply_lookup_table(self, ct, lut, exact=False):
+        return self.apply_lookup_table_batch(np.asarray(ct)[None, :], lut, exact=exact, threads=1)[0]
+
+    def trivial_pbs_body(self, body: int, lut) -> int:
+        return int(lib().orc_trivial_pbs_body(C.byref(self.params.c()), int(body), _a(lut)))
+
+
+def fft_roundtrip_product(N: int, torus_poly, int_poly):
+    """forward_as_torus(a) * forward_as_integer(b) -> add_backward_as_torus into zeros."""
+    f = lib().orc_fft_new(N)
+    fa = np.zeros(N, dtype=np.float64)
+    fb = np.zeros(N, dtype=np.float64)
+    lib().orc_fft_forward_as_torus(f, fa, _a(torus_poly))
+    lib().orc_fft_forward_as_integer(f, fb, _a(int_poly))
+    za = fa.view(np.complex128) * fb.view(np.complex128)
+    out = np.zeros(N, dtype=np.uint64)
+    lib().orc_fft_add_backward_as_torus(f, out, np.ascontiguousarray(za).view(np.float64))
+    lib().orc_fft_free(f)
+    return out
+
+
+def negacyclic_schoolbook(a, b):
+    """Exact negacyclic product mod (X^N+1, 2^64) with numpy wrapping arithmetic."""
+    a = _a(a)
+    b = _a(b)
+    N = len(a)
+    full = np.zeros(2 * N, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for i in range(N):
+            if a[i]:
+                full[i:i + N] += a[i] * b
+        return full[:N] - full[N:]

@@ -1,0 +1,723 @@
+/*
+ * tfhe_oracle.c -- CPU ORACLE (test infrastructure, NOT a product path).  See tfhe_oracle.h.
+ *
+ * Restates, function by function, the tfhe-rs 0.5.0 code under /root/reference/tfhe/src that
+ * the hot path runs.  Citations are file:line relative to that directory.
+ * Parity: integer-only functions are pinned by the reference doctest vectors
+ * (tests/test_oracle_kat.py); the f64 FFT bits are "parity unpinned" (concrete-fft 0.3.0 is
+ * not vendored) -- checked at tolerance / decrypt level exactly as the reference's own tests do.
+ */
+#define _GNU_SOURCE
+#include "tfhe_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+static inline uint64_t width_mask(uint32_t bits) { return bits >= 64 ? ~0ULL : ((1ULL << bits) - 1); }
+
+/* ------------------------------------------------------------------------------------------
+ * core_crypto/commons/math/decomposition/decomposer.rs:98-118  (closest_representable)
+ * ---------------------------------------------------------------------------------------- */
+uint64_t orc_closest_representable(uint64_t x, uint32_t base_log, uint32_t level, uint32_t bits) {
+    uint64_t m = width_mask(bits);
+    uint32_t non_rep_bit_count = bits - level * base_log;
+    uint32_t shift = non_rep_bit_count - 1;
+    uint64_t res = (x & m) >> shift;
+    res += 1;
+    res &= ~1ULL; /* Scalar::TWO.wrapping_neg() == ...1110 */
+    return (res << shift) & m;
+}
+
+/* core_crypto/commons/math/decomposition/iter.rs:120-127 (decompose_one_level) */
+static inline uint64_t decompose_one_level(uint32_t base_log, uint64_t *state, uint64_t mod_b_mask) {
+    uint64_t res = *state & mod_b_mask;
+    *state >>= base_log;
+    uint64_t carry = ((res - 1ULL) | *state) & res;
+    carry >>= base_log - 1;
+    *state += carry;
+    return res - (carry << base_log);
+}
+
+/* decomposer.rs:144-152 + iter.rs:37-50,101-117: digits[0] is level `level`, digits[level-1] is
+ * level 1 (the iterator yields terms in order of decreasing level). */
+void orc_decompose(uint64_t x, uint32_t base_log, uint32_t level, uint32_t bits, uint64_t *digits) {
+    uint64_t m = width_mask(bits);
+    uint64_t closest = orc_closest_representable(x, base_log, level, bits);
+    uint64_t state = closest >> (bits - base_log * level);
+    uint64_t mod_b_mask = (1ULL << base_log) - 1;
+    for (uint32_t i = 0; i < level; i++) digits[i] = decompose_one_level(base_log, &state, mod_b_mask) & m;
+}
+
+/* core_crypto/fft_impl/common.rs:26-43 with offset 0, lut_count_log 0 */
+uint64_t orc_modulus_switch(uint64_t x, uint32_t log2_poly_size) {
+    uint64_t out = x >> (64 - log2_poly_size - 2);
+    out += 1;
+    out >>= 1;
+    return out;
+}
+
+/* core_crypto/algorithms/polynomial_algorithms.rs:315-354 */
+void orc_monomial_div(uint64_t *out, const uint64_t *in, uint32_t N, uint64_t degree, uint32_t bits) {
+    uint64_t m = width_mask(bits);
+    uint64_t rem = degree % N;
+    uint64_t full = degree / N;
+    if (full % 2 == 0) {
+        for (uint64_t j = 0; j < N - rem; j++) out[j] = in[rem + j] & m;
+        for (uint64_t j = 0; j < rem; j++) out[N - rem + j] = (0 - in[j]) & m;
+    } else {
+        for (uint64_t j = 0; j < N - rem; j++) out[j] = (0 - in[rem + j]) & m;
+        for (uint64_t j = 0; j < rem; j++) out[N - rem + j] = in[j] & m;
+    }
+}
+
+/* core_crypto/algorithms/polynomial_algorithms.rs:375-414 (polynomial_wrapping_monic_monomial_mul) */
+void orc_monomial_mul(uint64_t *out, const uint64_t *in, uint32_t N, uint64_t degree, uint32_t bits) {
+    uint64_t m = width_mask(bits);
+    uint64_t rem = degree % N;
+    uint64_t full = degree / N;
+    if (full % 2 == 0) {
+        for (uint64_t j = 0; j < rem; j++) out[j] = (0 - in[N - rem + j]) & m;
+        for (uint64_t j = 0; j < N - rem; j++) out[rem + j] = in[j] & m;
+    } else {
+        for (uint64_t j = 0; j < rem; j++) out[j] = in[N - rem + j] & m;
+        for (uint64_t j = 0; j < N - rem; j++) out[rem + j] = (0 - in[j]) & m;
+    }
+}
+
+/* core_crypto/algorithms/polynomial_algorithms.rs:425-490: out = in * X^degree - in */
+void orc_monomial_mul_and_subtract(uint64_t *out, const uint64_t *in, uint32_t N, uint64_t degree,
+                                   uint32_t bits) {
+    uint64_t m = width_mask(bits);
+    uint64_t rem = degree % N;
+    uint64_t full = degree / N;
+    if (full % 2 == 0) {
+        for (uint64_t j = 0; j < rem; j++) out[j] = ((0 - in[N - rem + j]) - in[j]) & m;
+        for (uint64_t j = 0; j < N - rem; j++) out[rem + j] = (in[j] - in[rem + j]) & m;
+    } else {
+        for (uint64_t j = 0; j < rem; j++) out[j] = (in[N - rem + j] - in[j]) & m;
+        for (uint64_t j = 0; j < N - rem; j++) out[rem + j] = ((0 - in[j]) - in[rem + j]) & m;
+    }
+}
+
+/* core_crypto/algorithms/slice_algorithms.rs:363-399: out[i] -= in[i] * scalar */
+void orc_slice_sub_scalar_mul(uint64_t *out, const uint64_t *in, uint64_t scalar, size_t len,
+                              uint32_t bits) {
+    uint64_t m = width_mask(bits);
+    for (size_t i = 0; i < len; i++) out[i] = (out[i] - in[i] * scalar) & m;
+}
+
+/* Rust `f64 as i64`: saturating, NaN -> 0 */
+int64_t orc_f64_to_i64(double x) {
+    if (x != x) return 0;
+    if (x >= 9223372036854775808.0) return INT64_MAX;
+    if (x <= -9223372036854775808.0) return INT64_MIN;
+    return (int64_t)x;
+}
+
+/* core_crypto/commons/math/torus/mod.rs:72-78 (FromTorus<f64> for u64).
+ * Rust's f64::round rounds half away from zero == C round(). */
+uint64_t orc_from_torus(double x) {
+    double fract = x - round(x);
+    fract *= 18446744073709551616.0; /* 2^64 */
+    fract = round(fract);
+    return (uint64_t)orc_f64_to_i64(fract);
+}
+
+size_t orc_ksk_len(const orc_params *p) {
+    return (size_t)p->k * p->N * p->ks_level * (p->n + 1);
+}
+size_t orc_bsk_len(const orc_params *p) {
+    return (size_t)p->n * p->pbs_level * (p->k + 1) * (p->k + 1) * p->N;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * core_crypto/algorithms/lwe_keyswitch.rs:96-170
+ * KSK layout [in_dim][level (highest first)][out_lwe_size]  (entities/lwe_keyswitch_key.rs:77-108)
+ * ---------------------------------------------------------------------------------------- */
+void orc_keyswitch(const orc_params *p, const uint64_t *ksk, const uint64_t *in, uint64_t *out) {
+    const size_t in_dim = (size_t)p->k * p->N;
+    const size_t out_size = (size_t)p->n + 1;
+    uint64_t digits[64];
+    memset(out, 0, out_size * sizeof(uint64_t)); /* :143 */
+    out[out_size - 1] = in[in_dim];              /* :146 */
+    for (size_t i = 0; i < in_dim; i++) {
+        orc_decompose(in[i], p->ks_base_log, p->ks_level, 64, digits); /* :158 */
+        const uint64_t *block = ksk + i * p->ks_level * out_size;
+        for (uint32_t lv = 0; lv < p->ks_level; lv++) {
+            const uint64_t *row = block + (size_t)lv * out_size;
+            const uint64_t d = digits[lv];
+            for (size_t j = 0; j < out_size; j++) out[j] -= row[j] * d; /* :162-166 */
+        }
+    }
+}
+
+/* core_crypto/algorithms/glwe_sample_extraction.rs:91-147 with nth = 0 */
+void orc_sample_extract(const orc_params *p, const uint64_t *acc, uint64_t *lwe) {
+    const uint32_t N = p->N, k = p->k;
+    lwe[(size_t)k * N] = acc[(size_t)k * N + 0];
+    for (uint32_t q = 0; q < k; q++) {
+        const uint64_t *a = acc + (size_t)q * N;
+        uint64_t *o = lwe + (size_t)q * N;
+        /* reverse, negate first N-1, rotate-left by N-1  ==>  (a0, -a_{N-1}, ..., -a_1) */
+        o[0] = a[0];
+        for (uint32_t t = 1; t < N; t++) o[t] = 0 - a[N - t];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * f64 negacyclic FFT: core_crypto/fft_impl/fft64/math/fft/mod.rs
+ *   twisties           :58-69   w_j = exp(i*pi*j/N), j < N/2
+ *   forward conversions:197-239 (torus: i64 -> f64 * 2^-64 ; integer: i64 -> f64), then Plan::fwd
+ *   backward           :285-304 Plan::inv, * conj(w_j) / (N/2), from_torus, wrapping add
+ * The size-N/2 complex FFT itself is concrete-fft's (un-vendored): restated here as a textbook
+ * iterative radix-2 transform.  Output ordering / rounding therefore differ from the reference
+ * in the last bits ("parity unpinned"); all consumers only multiply pointwise and transform back.
+ * ---------------------------------------------------------------------------------------- */
+struct orc_fft {
+    uint32_t N, n;     /* n = N/2 */
+    double *tw_re, *tw_im;   /* twisties */
+    double *w_re, *w_im;     /* exp(-2*pi*i*j/n), j < n/2 */
+    uint32_t *rev;
+};
+
+orc_fft *orc_fft_new(uint32_t N) {
+    orc_fft *f = (orc_fft *)calloc(1, sizeof(orc_fft));
+    uint32_t n = N / 2;
+    f->N = N;
+    f->n = n;
+    f->tw_re = (double *)malloc(sizeof(double) * n);
+    f->tw_im = (double *)malloc(sizeof(double) * n);
+    f->w_re = (double *)malloc(sizeof(double) * (n / 2 + 1));
+    f->w_im = (double *)malloc(sizeof(double) * (n / 2 + 1));
+    f->rev = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    double unit = M_PI / (2.0 * (double)n);
+    for (uint32_t i = 0; i < n; i++) {
+        f->tw_re[i] = cos((double)i * unit);
+        f->tw_im[i] = sin((double)i * unit);
+    }
+    for (uint32_t i = 0; i < n / 2 + 1; i++) {
+        double a = -2.0 * M_PI * (double)i / (double)n;
+        f->w_re[i] = cos(a);
+        f->w_im[i] = sin(a);
+    }
+    uint32_t lg = 0;
+    while ((1u << lg) < n) lg++;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t r = 0;
+        for (uint32_t b = 0; b < lg; b++)
+            if (i & (1u << b)) r |= 1u << (lg - 1 - b);
+        f->rev[i] = r;
+    }
+    return f;
+}
+
+void orc_fft_free(orc_fft *f) {
+    if (!f) return;
+    free(f->tw_re);
+    free(f->tw_im);
+    free(f->w_re);
+    free(f->w_im);
+    free(f->rev);
+    free(f);
+}
+
+/* in-place complex FFT on interleaved data; sign=-1 forward (uses w), +1 inverse (conj w) */
+static void cfft(const orc_fft *f, double *d, int sign) {
+    const uint32_t n = f->n;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t r = f->rev[i];
+        if (r > i) {
+            double tr = d[2 * i], ti = d[2 * i + 1];
+            d[2 * i] = d[2 * r];
+            d[2 * i + 1] = d[2 * r + 1];
+            d[2 * r] = tr;
+            d[2 * r + 1] = ti;
+        }
+    }
+    for (uint32_t len = 2; len <= n; len <<= 1) {
+        uint32_t half = len / 2, step = n / len;
+        for (uint32_t s = 0; s < n; s += len) {
+            for (uint32_t j = 0; j < half; j++) {
+                double wr = f->w_re[j * step];
+                double wi = sign < 0 ? f->w_im[j * step] : -f->w_im[j * step];
+                double *a = d + 2 * (s + j), *b = d + 2 * (s + j + half);
+                double xr = b[0] * wr - b[1] * wi;
+                double xi = b[0] * wi + b[1] * wr;
+                b[0] = a[0] - xr;
+                b[1] = a[1] - xi;
+                a[0] += xr;
+                a[1] += xi;
+            }
+        }
+    }
+}
+
+static void fft_forward(const orc_fft *f, double *out, const uint64_t *poly, double scale) {
+    const uint32_t n = f->n;
+    for (uint32_t j = 0; j < n; j++) {
+        double re = (double)(int64_t)poly[j] * scale;       /* into_signed().cast_into() */
+        double im = (double)(int64_t)poly[j + n] * scale;
+        out[2 * j] = re * f->tw_re[j] - im * f->tw_im[j];
+        out[2 * j + 1] = re * f->tw_im[j] + im * f->tw_re[j];
+    }
+    cfft(f, out, -1);
+}
+
+void orc_fft_forward_as_integer(const orc_fft *f, double *out, const uint64_t *poly) {
+    fft_forward(f, out, poly, 1.0);
+}
+void orc_fft_forward_as_torus(const orc_fft *f, double *out, const uint64_t *poly) {
+    fft_forward(f, out, poly, 5.421010862427522e-20 /* 2^-64 */);
+}
+
+void orc_fft_add_backward_as_torus(const orc_fft *f, uint64_t *poly, double *d) {
+    const uint32_t n = f->n;
+    cfft(f, d, +1);
+    const double norm = 1.0 / (double)n;
+    for (uint32_t j = 0; j < n; j++) {
+        double wr = f->tw_re[j] * norm, wi = -f->tw_im[j] * norm;
+        double re = d[2 * j] * wr - d[2 * j + 1] * wi;
+        double im = d[2 * j] * wi + d[2 * j + 1] * wr;
+        poly[j] += orc_from_torus(re);
+        poly[j + n] += orc_from_torus(im);
+    }
+}
+
+/* core_crypto/algorithms/lwe_bootstrap_key_conversion.rs:99-152 + fft/mod.rs:719-764:
+ * every polynomial of the standard key is transformed with forward_as_torus. */
+void orc_bsk_to_fourier(const orc_params *p, const uint64_t *bsk_std, double *fbsk) {
+    orc_fft *f = orc_fft_new(p->N);
+    size_t polys = (size_t)p->n * p->pbs_level * (p->k + 1) * (p->k + 1);
+    for (size_t i = 0; i < polys; i++)
+        orc_fft_forward_as_torus(f, fbsk + i * p->N /* N/2 complex = N doubles */, bsk_std + i * p->N);
+    orc_fft_free(f);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * core_crypto/fft_impl/fft64/crypto/ggsw.rs:477-598 (add_external_product_assign)
+ * fggsw layout [level idx (0 = level 1)][row][col][N/2 complex]   (ggsw.rs:154-166,227-241)
+ * ---------------------------------------------------------------------------------------- */
+void orc_add_external_product_fft(const orc_params *p, const orc_fft *f, uint64_t *out,
+                                  const double *fggsw, const uint64_t *glwe) {
+    const uint32_t N = p->N, k1 = p->k + 1, L = p->pbs_level, b = p->pbs_base_log;
+    const size_t G = (size_t)k1 * N;
+    uint64_t *state = (uint64_t *)malloc(G * sizeof(uint64_t));
+    uint64_t *digit = (uint64_t *)malloc(G * sizeof(uint64_t));
+    double *fourier = (double *)malloc(N * sizeof(double));
+    double *outf = (double *)calloc((size_t)k1 * N, sizeof(double));
+    const uint64_t mod_b_mask = (1ULL << b) - 1;
+    /* :514-518 + fft64/math/decomposition.rs:33-35 */
+    for (size_t j = 0; j < G; j++)
+        state[j] = orc_closest_representable(glwe[j], b, L, 64) >> (64 - b * L);
+    int uninit = 1;
+    for (uint32_t it = 0; it < L; it++) {
+        uint32_t lvl_idx = L - 1 - it; /* ggsw.into_levels().rev()  :524 */
+        for (size_t j = 0; j < G; j++) digit[j] = decompose_one_level(b, &state[j], mod_b_mask);
+        for (uint32_t row = 0; row < k1; row++) {
+            orc_fft_forward_as_integer(f, fourier, digit + (size_t)row * N); /* :556-562 */
+            const double *ggsw_row = fggsw + ((size_t)lvl_idx * k1 + row) * k1 * N;
+            for (uint32_t col = 0; col < k1; col++) { /* update_with_fmadd :616-697 */
+                const double *g = ggsw_row + (size_t)col * N;
+                double *o = outf + (size_t)col * N;
+                for (uint32_t j = 0; j < N / 2; j++) {
+                    double gr = g[2 * j], gi = g[2 * j + 1], fr = fourier[2 * j], fi = fourier[2 * j + 1];
+                    double pr = gr * fr - gi * fi, pi = gr * fi + gi * fr;
+                    if (uninit) {
+                        o[2 * j] = pr;
+                        o[2 * j + 1] = pi;
+                    } else {
+                        o[2 * j] += pr;
+                        o[2 * j + 1] += pi;
+                    }
+                }
+            }
+            uninit = 0;
+        }
+    }
+    for (uint32_t col = 0; col < k1; col++) /* :585-597 */
+        orc_fft_add_backward_as_torus(f, out + (size_t)col * N, outf + (size_t)col * N);
+    free(state);
+    free(digit);
+    free(fourier);
+    free(outf);
+}
+
+/* Exact-integer twin: out[col] += sum_lvl sum_row digit[lvl][row] (*) ggsw_std[lvl][row][col]
+ * (negacyclic, mod 2^64).  Ground truth the f64 path approximates. */
+void orc_add_external_product_exact(const orc_params *p, uint64_t *out, const uint64_t *ggsw,
+                                    const uint64_t *glwe) {
+    const uint32_t N = p->N, k1 = p->k + 1, L = p->pbs_level, b = p->pbs_base_log;
+    const size_t G = (size_t)k1 * N;
+    uint64_t *state = (uint64_t *)malloc(G * sizeof(uint64_t));
+    uint64_t *digit = (uint64_t *)malloc(G * sizeof(uint64_t));
+    uint64_t *tmp = (uint64_t *)malloc(2 * (size_t)N * sizeof(uint64_t));
+    const uint64_t mod_b_mask = (1ULL << b) - 1;
+    for (size_t j = 0; j < G; j++)
+        state[j] = orc_closest_representable(glwe[j], b, L, 64) >> (64 - b * L);
+    for (uint32_t it = 0; it < L; it++) {
+        uint32_t lvl_idx = L - 1 - it;
+        for (size_t j = 0; j < G; j++) digit[j] = decompose_one_level(b, &state[j], mod_b_mask);
+        for (uint32_t row = 0; row < k1; row++) {
+            const uint64_t *d = digit + (size_t)row * N;
+            for (uint32_t col = 0; col < k1; col++) {
+                const uint64_t *g = ggsw + (((size_t)lvl_idx * k1 + row) * k1 + col) * N;
+                memset(tmp, 0, 2 * (size_t)N * sizeof(uint64_t));
+                for (uint32_t a = 0; a < N; a++) {
+                    uint64_t da = d[a];
+                    if (!da) continue;
+                    uint64_t *t = tmp + a;
+                    for (uint32_t c = 0; c < N; c++) t[c] += da * g[c];
+                }
+                uint64_t *o = out + (size_t)col * N;
+                for (uint32_t c = 0; c < N; c++) o[c] += tmp[c] - tmp[c + N];
+            }
+        }
+    }
+    free(state);
+    free(digit);
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * core_crypto/fft_impl/fft64/crypto/bootstrap.rs:242-331 (blind_rotate_assign)
+ * ---------------------------------------------------------------------------------------- */
+static uint32_t ilog2(uint32_t x) {
+    uint32_t l = 0;
+    while ((1u << l) < x) l++;
+    return l;
+}
+
+static void blind_rotate(const orc_params *p, const orc_fft *f, const double *fbsk,
+                         const uint64_t *bsk_std, const uint64_t *lwe, uint64_t *acc) {
+    const uint32_t N = p->N, k1 = p->k + 1, n = p->n;
+    const size_t G = (size_t)k1 * N;
+    const uint32_t logN = ilog2(N);
+    uint64_t *tmp = (uint64_t *)malloc(G * sizeof(uint64_t));
+    /* :254-271  acc <- acc * X^{-ms(body)} */
+    uint64_t deg = orc_modulus_switch(lwe[n], logN);
+    for (uint32_t q = 0; q < k1; q++) {
+        memcpy(tmp, acc + (size_t)q * N, N * sizeof(uint64_t));
+        orc_monomial_div(acc + (size_t)q * N, tmp, N, deg, 64);
+    }
+    const size_t ggsw_polys = (size_t)p->pbs_level * k1 * k1;
+    for (uint32_t i = 0; i < n; i++) {
+        if (lwe[i] == 0) continue; /* :281 */
+        uint64_t d = orc_modulus_switch(lwe[i], logN);
+        for (uint32_t q = 0; q < k1; q++) /* :293-303  ct1 = acc*X^d - acc */
+            orc_monomial_mul_and_subtract(tmp + (size_t)q * N, acc + (size_t)q * N, N, d, 64);
+        if (fbsk)
+            orc_add_external_product_fft(p, f, acc, fbsk + (size_t)i * ggsw_polys * N, tmp);
+        else
+            orc_add_external_product_exact(p, acc, bsk_std + (size_t)i * ggsw_polys * N, tmp);
+    }
+    free(tmp);
+}
+
+void orc_blind_rotate_fft(const orc_params *p, const orc_fft *f, const double *fbsk,
+                          const uint64_t *lwe, uint64_t *acc) {
+    blind_rotate(p, f, fbsk, NULL, lwe, acc);
+}
+void orc_blind_rotate_exact(const orc_params *p, const uint64_t *bsk_std, const uint64_t *lwe,
+                            uint64_t *acc) {
+    blind_rotate(p, NULL, NULL, bsk_std, lwe, acc);
+}
+
+/* bootstrap.rs:333-364: copy LUT, blind rotate, sample extract */
+void orc_pbs_fft(const orc_params *p, const orc_fft *f, const double *fbsk, const uint64_t *lwe,
+                 const uint64_t *lut, uint64_t *out) {
+    size_t G = (size_t)(p->k + 1) * p->N;
+    uint64_t *acc = (uint64_t *)malloc(G * sizeof(uint64_t));
+    memcpy(acc, lut, G * sizeof(uint64_t));
+    blind_rotate(p, f, fbsk, NULL, lwe, acc);
+    orc_sample_extract(p, acc, out);
+    free(acc);
+}
+void orc_pbs_exact(const orc_params *p, const uint64_t *bsk_std, const uint64_t *lwe,
+                   const uint64_t *lut, uint64_t *out) {
+    size_t G = (size_t)(p->k + 1) * p->N;
+    uint64_t *acc = (uint64_t *)malloc(G * sizeof(uint64_t));
+    memcpy(acc, lut, G * sizeof(uint64_t));
+    blind_rotate(p, NULL, NULL, bsk_std, lwe, acc);
+    orc_sample_extract(p, acc, out);
+    free(acc);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * shortint/server_key/mod.rs:783-857 (keyswitch_programmable_bootstrap_assign), batched the way
+ * benches/core_crypto/pbs_bench.rs:517-532 does it: independent LWEs over worker threads.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const orc_params *p;
+    const uint64_t *ksk;
+    const double *fbsk;
+    const uint64_t *bsk_std;
+    int exact;
+    const uint64_t *in;
+    const uint32_t *lut_idx;
+    const uint64_t *luts;
+    uint64_t *out;
+    size_t lo, hi;
+} ks_pbs_job;
+
+static void *ks_pbs_worker(void *arg) {
+    ks_pbs_job *j = (ks_pbs_job *)arg;
+    const orc_params *p = j->p;
+    const size_t big = (size_t)p->k * p->N + 1, G = (size_t)(p->k + 1) * p->N;
+    uint64_t *small = (uint64_t *)malloc(((size_t)p->n + 1) * sizeof(uint64_t));
+    orc_fft *f = j->exact ? NULL : orc_fft_new(p->N);
+    for (size_t i = j->lo; i < j->hi; i++) {
+        orc_keyswitch(p, j->ksk, j->in + i * big, small);
+        const uint64_t *lut = j->luts + (j->lut_idx ? (size_t)j->lut_idx[i] * G : 0);
+        if (j->exact)
+            orc_pbs_exact(p, j->bsk_std, small, lut, j->out + i * big);
+        else
+            orc_pbs_fft(p, f, j->fbsk, small, lut, j->out + i * big);
+    }
+    orc_fft_free(f);
+    free(small);
+    return NULL;
+}
+
+void orc_ks_pbs_batch(const orc_params *p, const uint64_t *ksk, const double *fbsk,
+                      const uint64_t *bsk_std, int exact, const uint64_t *in,
+                      const uint32_t *lut_idx, const uint64_t *luts, uint64_t *out, size_t count,
+                      int threads) {
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > count) threads = (int)(count ? count : 1);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    ks_pbs_job *jobs = (ks_pbs_job *)malloc(sizeof(ks_pbs_job) * threads);
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = (ks_pbs_job){p, ksk, fbsk, bsk_std, exact, in, lut_idx, luts, out,
+                               count * t / threads, count * (t + 1) / threads};
+        if (threads == 1)
+            ks_pbs_worker(&jobs[t]);
+        else
+            pthread_create(&th[t], NULL, ks_pbs_worker, &jobs[t]);
+    }
+    if (threads > 1)
+        for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    free(th);
+    free(jobs);
+}
+
+/* shortint/engine/mod.rs:72-128 (fill_accumulator) */
+uint64_t orc_fill_accumulator(const orc_params *p, const uint64_t *table, uint64_t *lut) {
+    const uint32_t N = p->N, k = p->k;
+    memset(lut, 0, (size_t)k * N * sizeof(uint64_t)); /* mask = 0  :92 */
+    uint64_t *body = lut + (size_t)k * N;
+    const uint32_t modulus_sup = p->msg_mod * p->carry_mod;
+    const uint32_t box = N / modulus_sup;
+    const uint64_t delta = (1ULL << 63) / modulus_sup;
+    uint64_t maxv = 0;
+    for (uint32_t i = 0; i < modulus_sup; i++) {
+        uint64_t fe = table[i];
+        if (fe > maxv) maxv = fe;
+        for (uint32_t j = 0; j < box; j++) body[i * box + j] = fe * delta;
+    }
+    const uint32_t half = box / 2;
+    for (uint32_t j = 0; j < half; j++) body[j] = 0 - body[j]; /* :120-122 */
+    /* rotate_left(half) :125 */
+    uint64_t *tmp = (uint64_t *)malloc(N * sizeof(uint64_t));
+    for (uint32_t j = 0; j < N; j++) tmp[j] = body[(j + half) % N];
+    memcpy(body, tmp, N * sizeof(uint64_t));
+    free(tmp);
+    return maxv;
+}
+
+/* shortint/server_key/mod.rs:763-781 (trivial_pbs_assign) */
+uint64_t orc_trivial_pbs_body(const orc_params *p, uint64_t body_in, const uint64_t *lut) {
+    const uint32_t modulus_sup = p->msg_mod * p->carry_mod;
+    const uint64_t delta = (1ULL << 63) / modulus_sup;
+    const uint32_t box = p->N / modulus_sup;
+    const uint64_t *body = lut + (size_t)p->k * p->N;
+    uint64_t v = body_in / delta;
+    if (v >= modulus_sup) return 0 - body[(v % modulus_sup) * box];
+    return body[v * box];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Harness.  The reference draws randomness from an AES-CTR CSPRNG (concrete-csprng, out of
+ * scope: never used during evaluation); the harness uses xoshiro256** seeded by splitmix64 so
+ * that fixtures are reproducible from a seed.
+ * ---------------------------------------------------------------------------------------- */
+static inline uint64_t splitmix64(uint64_t *x) {
+    uint64_t z = (*x += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+void orc_rng_init(orc_rng *r, uint64_t seed, uint64_t stream) {
+    uint64_t x = seed ^ (stream * 0xD1342543DE82EF95ULL + 0x2545F4914F6CDD1DULL);
+    for (int i = 0; i < 4; i++) r->s[i] = splitmix64(&x);
+}
+uint64_t orc_rng_next(orc_rng *r) {
+    uint64_t *s = r->s;
+    uint64_t result = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl(s[3], 45);
+    return result;
+}
+
+/* core_crypto/commons/math/random/gaussian.rs:17-47 (Marsaglia polar method on two i64 draws) */
+void orc_rng_gaussian_pair(orc_rng *r, double std, double *a, double *b) {
+    for (;;) {
+        double u = (double)(int64_t)orc_rng_next(r) * 1.0842021724855044e-19; /* 2^-63 */
+        double v = (double)(int64_t)orc_rng_next(r) * 1.0842021724855044e-19;
+        double s = u * u + v * v;
+        if (s > 0.0 && s < 1.0) {
+            double cst = std * sqrt(-2.0 * log(s) / s);
+            *a = u * cst;
+            *b = v * cst;
+            return;
+        }
+    }
+}
+static uint64_t gaussian_torus(orc_rng *r, double std) { /* gaussian.rs:85-97: first of the pair */
+    double a, b;
+    orc_rng_gaussian_pair(r, std, &a, &b);
+    return orc_from_torus(a);
+}
+
+/* shortint/engine/client_side.rs:13-27: uniform binary secret keys */
+void orc_gen_binary_key(uint64_t seed, uint64_t stream, uint64_t *key, size_t len) {
+    orc_rng r;
+    orc_rng_init(&r, seed, stream);
+    for (size_t i = 0; i < len; i += 64) {
+        uint64_t w = orc_rng_next(&r);
+        for (size_t b = 0; b < 64 && i + b < len; b++) key[i + b] = (w >> b) & 1;
+    }
+}
+
+/* core_crypto/algorithms/lwe_encryption.rs:61-110: mask uniform, body = <a,s> + e + pt */
+void orc_lwe_encrypt(const uint64_t *sk, size_t dim, uint64_t pt, double std, orc_rng *r,
+                     uint64_t *ct) {
+    uint64_t acc = 0;
+    for (size_t i = 0; i < dim; i++) {
+        ct[i] = orc_rng_next(r);
+        acc += ct[i] * sk[i];
+    }
+    ct[dim] = acc + gaussian_torus(r, std) + pt;
+}
+/* core_crypto/algorithms/lwe_encryption.rs (decrypt_lwe_ciphertext): body - <a,s> */
+uint64_t orc_lwe_decrypt(const uint64_t *sk, size_t dim, const uint64_t *ct) {
+    uint64_t acc = 0;
+    for (size_t i = 0; i < dim; i++) acc += ct[i] * sk[i];
+    return ct[dim] - acc;
+}
+
+/* core_crypto/algorithms/glwe_encryption.rs:17-60: mask uniform; body += e; body += sum A_q*S_q.
+ * Binary key => the negacyclic product is a sum of signed shifts of A_q. */
+void orc_glwe_encrypt_assign(const orc_params *p, const uint64_t *sk, uint64_t *glwe, double std,
+                             orc_rng *r) {
+    const uint32_t N = p->N, k = p->k;
+    uint64_t *body = glwe + (size_t)k * N;
+    for (size_t j = 0; j < (size_t)k * N; j++) glwe[j] = orc_rng_next(r);
+    for (uint32_t j = 0; j < N; j++) body[j] += gaussian_torus(r, std);
+    for (uint32_t q = 0; q < k; q++) {
+        const uint64_t *a = glwe + (size_t)q * N, *s = sk + (size_t)q * N;
+        for (uint32_t t = 0; t < N; t++) {
+            if (!s[t]) continue;
+            for (uint32_t c = 0; c < N - t; c++) body[c + t] += a[c];
+            for (uint32_t c = N - t; c < N; c++) body[c + t - N] -= a[c];
+        }
+    }
+}
+
+/* core_crypto/algorithms/lwe_keyswitch_key_generation.rs:65-130: for each input key bit, an LWE
+ * list under the small key encrypting bit << (64 - b*level), level = l..1 (highest first). */
+void orc_gen_ksk(const orc_params *p, const uint64_t *big_sk, const uint64_t *small_sk,
+                 uint64_t seed, uint64_t *ksk) {
+    const size_t in_dim = (size_t)p->k * p->N, osz = (size_t)p->n + 1;
+    for (size_t i = 0; i < in_dim; i++) {
+        orc_rng r;
+        orc_rng_init(&r, seed, 0x4B534B0000000000ULL + i);
+        for (uint32_t it = 0; it < p->ks_level; it++) {
+            uint32_t level = p->ks_level - it;
+            uint64_t pt = big_sk[i] << (64 - p->ks_base_log * level);
+            orc_lwe_encrypt(small_sk, p->n, pt, p->lwe_std, &r, ksk + (i * p->ks_level + it) * osz);
+        }
+    }
+}
+
+/* core_crypto/algorithms/lwe_bootstrap_key_generation.rs:76-135 + ggsw_encryption.rs:72-151,300-331 */
+typedef struct {
+    const orc_params *p;
+    const uint64_t *small_sk, *glwe_sk;
+    uint64_t seed;
+    uint64_t *bsk;
+    size_t lo, hi;
+} bsk_job;
+
+static void *bsk_worker(void *arg) {
+    bsk_job *j = (bsk_job *)arg;
+    const orc_params *p = j->p;
+    const uint32_t N = p->N, k = p->k, k1 = k + 1, L = p->pbs_level;
+    const size_t glwe_len = (size_t)k1 * N, ggsw_len = (size_t)L * k1 * glwe_len;
+    for (size_t i = j->lo; i < j->hi; i++) {
+        orc_rng r;
+        orc_rng_init(&r, j->seed, 0x42534B0000000000ULL + i);
+        uint64_t *ggsw = j->bsk + i * ggsw_len;
+        uint64_t m = j->small_sk[i];
+        for (uint32_t li = 0; li < L; li++) {
+            uint32_t level = li + 1;
+            uint64_t factor = (0 - m) * (1ULL << (64 - p->pbs_base_log * level)); /* :122-126 */
+            for (uint32_t row = 0; row < k1; row++) {
+                uint64_t *glwe = ggsw + ((size_t)li * k1 + row) * glwe_len;
+                uint64_t *body = glwe + (size_t)k * N;
+                if (row < k) { /* :313-323 */
+                    const uint64_t *s = j->glwe_sk + (size_t)row * N;
+                    for (uint32_t c = 0; c < N; c++) body[c] = s[c] * factor;
+                } else { /* :324-329 */
+                    memset(body, 0, N * sizeof(uint64_t));
+                    body[0] = 0 - factor;
+                }
+                orc_glwe_encrypt_assign(p, j->glwe_sk, glwe, p->glwe_std, &r);
+            }
+        }
+    }
+    return NULL;
+}
+
+void orc_gen_bsk(const orc_params *p, const uint64_t *small_sk, const uint64_t *glwe_sk,
+                 uint64_t seed, uint64_t *bsk, int threads) {
+    if (threads < 1) threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    bsk_job *jobs = (bsk_job *)malloc(sizeof(bsk_job) * threads);
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = (bsk_job){p, small_sk, glwe_sk, seed, bsk, (size_t)p->n * t / threads,
+                            (size_t)p->n * (t + 1) / threads};
+        if (threads == 1)
+            bsk_worker(&jobs[t]);
+        else
+            pthread_create(&th[t], NULL, bsk_worker, &jobs[t]);
+    }
+    if (threads > 1)
+        for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    free(th);
+    free(jobs);
+}
+
+/* shortint/engine/client_side.rs:66-74 */
+uint64_t orc_encode(const orc_params *p, uint64_t msg) {
+    uint64_t delta = (1ULL << 63) / ((uint64_t)p->msg_mod * p->carry_mod);
+    return msg * delta;
+}
+/* shortint/client_key/mod.rs:281-303 (decrypt_message_and_carry, after the LWE decryption) */
+uint64_t orc_decode(const orc_params *p, uint64_t x) {
+    uint64_t delta = (1ULL << 63) / ((uint64_t)p->msg_mod * p->carry_mod);
+    uint64_t rounding_bit = delta >> 1;
+    uint64_t rounding = (x & rounding_bit) << 1;
+    return (x + rounding) / delta;
+}
