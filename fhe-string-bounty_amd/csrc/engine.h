@@ -1,0 +1,67 @@
+// engine.h -- internal C++ interface of the engine (the public surface is include/fhestr.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/fhestr.h"
+
+namespace fhe {
+
+extern thread_local std::string g_last_error;
+int fail(const std::string& msg);
+
+struct BrVariant;
+
+struct Engine {
+    fhe_params_t p{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    const BrVariant* variant = nullptr;
+
+    // resident keys / tables
+    uint64_t* d_ksk = nullptr;
+    double* d_fbsk = nullptr;
+    uint64_t* d_luts = nullptr;
+    size_t luts_cap = 0;
+    uint32_t n_luts = 0;
+
+    // staging / scratch (grown on demand)
+    uint64_t *d_in = nullptr, *d_small = nullptr, *d_out = nullptr, *d_pool = nullptr;
+    uint32_t* d_idx = nullptr;
+    void* d_meta = nullptr;
+    size_t cap_in = 0, cap_small = 0, cap_out = 0, cap_idx = 0, cap_pool = 0, cap_meta = 0;
+
+    static int create(const fhe_params_t& p, int device, Engine** out);
+    ~Engine();
+    int use();
+    int set_variant(int logR);
+    int load_keys(const uint64_t* bsk_std, const uint64_t* ksk);
+    uint64_t fill_accumulator(const uint64_t* table, std::vector<uint64_t>& acc) const;
+    int lut_upload(const uint64_t* acc, uint32_t* id);
+    int lut_download(uint32_t id, uint64_t* acc);
+    int ensure_batch(uint32_t count);
+    int check_lut_idx(const uint32_t* lut_idx, uint32_t count) const;
+
+    int launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t count);
+    int launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx, uint64_t* d_big, uint32_t count);
+    int ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint64_t* d_big_out, uint32_t count);
+    int ks_pbs_host(const uint64_t* in, const uint32_t* lut_idx, uint64_t* out, uint32_t count);
+    int keyswitch_host(const uint64_t* in, uint64_t* out_small, uint32_t count);
+    int pbs_host(const uint64_t* in_small, const uint32_t* lut_idx, uint64_t* out, uint32_t count);
+    int lincomb_dev(const uint64_t* d_pool, const uint32_t* d_off, const uint32_t* d_src,
+                    const int32_t* d_coeff, const uint64_t* d_cst, uint64_t* d_out, uint32_t jobs);
+    int lincomb_host(const uint64_t* pool, uint32_t pool_count, const uint32_t* off, const uint32_t* src,
+                     const int32_t* coeff, const uint64_t* cst, uint64_t* out, uint32_t jobs);
+    int last_kernel_ms(float ms[2]);
+    int synchronize();
+};
+
+}  // namespace fhe
+
+struct fhe_engine {
+    fhe::Engine* impl;
+};

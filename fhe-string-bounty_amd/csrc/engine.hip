@@ -1,0 +1,365 @@
+// engine.hip -- host side of libfhestr.so: device memory, key residency, kernel dispatch.
+//
+// The reference keeps a ServerKey {key_switching_key, bootstrapping_key (Fourier)} in host memory
+// and runs one ciphertext at a time through thread-local scratch
+// (shortint/server_key/mod.rs:783-857, shortint/engine/mod.rs:184-234).  Here the keys are made
+// resident in HBM once (BSK 48.6 MB + KSK 60.9 MB for PARAM_MESSAGE_2_CARRY_2: both sit in the
+// 256 MB Infinity Cache) and whole batches of LWEs go through three launches on one HIP stream:
+// memset -> keyswitch_kernel -> blind_rotate_kernel.
+#include "engine.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "lwe_kernels.hip.h"
+#include "pbs_kernels.hip.h"
+
+namespace fhe {
+
+thread_local std::string g_last_error;
+
+int fail(const std::string& msg) {
+    g_last_error = msg;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+    } while (0)
+
+// ---- blind-rotation variant registry ----------------------------------------------------------
+struct BrVariant {
+    int logN, k1, L, logR;
+    int threads;
+    size_t lds_bytes;
+    size_t convert_lds;
+    const void* rotate_fn;
+    const void* convert_fn;
+};
+
+template <int LOGN, int LOGR, int K1, int L>
+BrVariant make_variant() {
+    using CFG = BrCfg<LOGN, LOGR, K1, L>;
+    BrVariant v;
+    v.logN = LOGN; v.k1 = K1; v.L = L; v.logR = LOGR;
+    v.threads = CFG::THREADS;
+    v.lds_bytes = CFG::LDS_BYTES;
+    v.convert_lds = (size_t)K1 * 2 * CFG::P * 8;
+    v.rotate_fn = reinterpret_cast<const void*>(&blind_rotate_kernel<LOGN, LOGR, K1, L>);
+    v.convert_fn = reinterpret_cast<const void*>(&bsk_convert_kernel<LOGN, LOGR, K1, L>);
+    return v;
+}
+
+static const std::vector<BrVariant>& variants() {
+    static const std::vector<BrVariant> v = {
+        // PARAM_MESSAGE_2_CARRY_2_KS_PBS: N=2048, k=1, l=1  (first entry of a shape = default)
+        make_variant<11, 3, 2, 1>(), make_variant<11, 2, 2, 1>(), make_variant<11, 4, 2, 1>(),
+        // N=1024, k=2, l=1 family (PARAM_MESSAGE_2_CARRY_1_KS_PBS ...)
+        make_variant<10, 3, 3, 1>(), make_variant<10, 2, 3, 1>(),
+        // PARAM_MESSAGE_1_CARRY_1_KS_PBS: N=512, k=3, l=1
+        make_variant<9, 2, 4, 1>(),
+        // toy shapes used by the fast tests
+        make_variant<8, 2, 2, 2>(), make_variant<7, 2, 3, 1>(),
+    };
+    return v;
+}
+
+static const BrVariant* find_variant(const fhe_params_t& p, int logR) {
+    int logN = 0;
+    while ((1u << logN) < p.N) logN++;
+    for (const auto& v : variants())
+        if (v.logN == logN && v.k1 == (int)p.k + 1 && v.L == (int)p.pbs_level &&
+            (logR == 0 || v.logR == logR))
+            return &v;
+    return nullptr;
+}
+
+// ---- Engine -----------------------------------------------------------------------------------
+int Engine::create(const fhe_params_t& p, int device, Engine** out) {
+    if ((p.N & (p.N - 1)) || p.N < 128) return fail("polynomial size must be a power of two >= 128");
+    if (p.pbs_base_log * p.pbs_level > 31 || p.pbs_base_log < 1)
+        return fail("pbs_base_log * pbs_level must be in [1, 31]");
+    if (p.ks_base_log < 1 || p.ks_base_log > 7 || p.ks_base_log * p.ks_level > 62)
+        return fail("unsupported keyswitch decomposition");
+    if (p.msg_mod * p.carry_mod == 0 || (p.N % (p.msg_mod * p.carry_mod)) != 0)
+        return fail("msg_mod * carry_mod must divide N");
+    int env_logr = 0;
+    if (const char* e = getenv("FHESTR_LOG2_POINTS")) env_logr = atoi(e);
+    const BrVariant* v = find_variant(p, env_logr);
+    if (!v) return fail("no blind-rotation kernel instantiated for this (N, k, level)");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (count <= 0) return fail("no HIP device: libfhestr has no CPU fallback");
+    if (device < 0 || device >= count) return fail("bad device index");
+    HIP_TRY(hipSetDevice(device));
+    Engine* e = new Engine();
+    e->p = p;
+    e->device = device;
+    e->variant = v;
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (auto& ev : e->ev) HIP_TRY(hipEventCreate(&ev));
+    *out = e;
+    return 0;
+}
+
+Engine::~Engine() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    auto rel = [](void* ptr) { if (ptr) (void)hipFree(ptr); };
+    rel(d_ksk); rel(d_fbsk); rel(d_luts); rel(d_in); rel(d_small); rel(d_out); rel(d_idx);
+    rel(d_pool); rel(d_meta);
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+int Engine::use() { HIP_TRY(hipSetDevice(device)); return 0; }
+
+static int ensure(void** ptr, size_t* cap, size_t bytes) {
+    if (*cap >= bytes) return 0;
+    if (*ptr) HIP_TRY(hipFree(*ptr));
+    *ptr = nullptr; *cap = 0;
+    HIP_TRY(hipMalloc(ptr, bytes));
+    *cap = bytes;
+    return 0;
+}
+
+int Engine::set_variant(int logR) {
+    const BrVariant* v = find_variant(p, logR);
+    if (!v) return fail("no such blind-rotation variant for these parameters");
+    if (v == variant) return 0;
+    if (d_fbsk && v->logR != variant->logR)
+        return fail("variant must be chosen before fhe_engine_load_keys (Fourier key layout depends on it)");
+    variant = v;
+    return 0;
+}
+
+int Engine::load_keys(const uint64_t* bsk_std, const uint64_t* ksk) {
+    if (use()) return 1;
+    const size_t ksk_len = (size_t)p.k * p.N * p.ks_level * (p.n + 1);
+    const size_t bsk_len = (size_t)p.n * p.pbs_level * (p.k + 1) * (p.k + 1) * p.N;
+    if (d_ksk) { HIP_TRY(hipFree(d_ksk)); d_ksk = nullptr; }
+    if (d_fbsk) { HIP_TRY(hipFree(d_fbsk)); d_fbsk = nullptr; }
+    HIP_TRY(hipMalloc((void**)&d_ksk, ksk_len * 8));
+    HIP_TRY(hipMemcpyAsync(d_ksk, ksk, ksk_len * 8, hipMemcpyHostToDevice, stream));
+    uint64_t* d_std = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_std, bsk_len * 8));
+    HIP_TRY(hipMalloc((void**)&d_fbsk, bsk_len * 8));   // N u64 -> N/2 c64: same byte count
+    HIP_TRY(hipMemcpyAsync(d_std, bsk_std, bsk_len * 8, hipMemcpyHostToDevice, stream));
+    const uint32_t n_polys = (uint32_t)(bsk_len / p.N);
+    const uint32_t k1 = p.k + 1;
+    void* args[] = {(void*)&d_std, (void*)&d_fbsk, (void*)&n_polys};
+    HIP_TRY(hipFuncSetAttribute(variant->convert_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)variant->convert_lds));
+    HIP_TRY(hipLaunchKernel(variant->convert_fn, dim3((n_polys + k1 - 1) / k1), dim3(variant->threads),
+                            args, variant->convert_lds, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipFree(d_std));
+    HIP_TRY(hipFuncSetAttribute(variant->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)variant->lds_bytes));
+    return 0;
+}
+
+// fill_accumulator: shortint/engine/mod.rs:72-128
+uint64_t Engine::fill_accumulator(const uint64_t* table, std::vector<uint64_t>& acc) const {
+    const uint32_t N = p.N, k = p.k;
+    acc.assign((size_t)(k + 1) * N, 0);
+    uint64_t* body = acc.data() + (size_t)k * N;
+    const uint32_t modulus_sup = p.msg_mod * p.carry_mod;
+    const uint32_t box = N / modulus_sup;
+    const uint64_t delta = (1ull << 63) / modulus_sup;
+    uint64_t maxv = 0;
+    std::vector<uint64_t> tmp(N);
+    for (uint32_t i = 0; i < modulus_sup; i++) {
+        maxv = table[i] > maxv ? table[i] : maxv;
+        for (uint32_t j = 0; j < box; j++) tmp[(size_t)i * box + j] = table[i] * delta;
+    }
+    const uint32_t half = box / 2;
+    for (uint32_t j = 0; j < half; j++) tmp[j] = 0 - tmp[j];
+    for (uint32_t j = 0; j < N; j++) body[j] = tmp[(j + half) % N];   // rotate_left(half)
+    return maxv;
+}
+
+int Engine::lut_upload(const uint64_t* acc, uint32_t* id) {
+    if (use()) return 1;
+    const size_t glwe = (size_t)(p.k + 1) * p.N;
+    if ((size_t)(n_luts + 1) * glwe * 8 > luts_cap) {
+        size_t new_cap = luts_cap ? luts_cap * 2 : 64 * glwe * 8;
+        uint64_t* nl = nullptr;
+        HIP_TRY(hipMalloc((void**)&nl, new_cap));
+        if (d_luts) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipMemcpy(nl, d_luts, (size_t)n_luts * glwe * 8, hipMemcpyDeviceToDevice));
+            HIP_TRY(hipFree(d_luts));
+        }
+        d_luts = nl;
+        luts_cap = new_cap;
+    }
+    HIP_TRY(hipMemcpyAsync(d_luts + (size_t)n_luts * glwe, acc, glwe * 8, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *id = n_luts++;
+    return 0;
+}
+
+int Engine::lut_download(uint32_t id, uint64_t* acc) {
+    if (use()) return 1;
+    if (id >= n_luts) return fail("bad LUT id");
+    const size_t glwe = (size_t)(p.k + 1) * p.N;
+    HIP_TRY(hipMemcpyAsync(acc, d_luts + (size_t)id * glwe, glwe * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int Engine::ensure_batch(uint32_t count) {
+    const size_t big = (size_t)p.k * p.N + 1, small = (size_t)p.n + 1;
+    if (ensure((void**)&d_in, &cap_in, count * big * 8)) return 1;
+    if (ensure((void**)&d_out, &cap_out, count * big * 8)) return 1;
+    if (ensure((void**)&d_small, &cap_small, count * small * 8)) return 1;
+    if (ensure((void**)&d_idx, &cap_idx, (size_t)count * 4)) return 1;
+    return 0;
+}
+
+int Engine::launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t count) {
+    if (!d_ksk) return fail("keys not loaded");
+    const uint32_t in_dim = p.k * p.N, out_size = p.n + 1;
+    HIP_TRY(hipMemsetAsync(d_sm, 0, (size_t)count * out_size * 8, stream));
+    KeyswitchArgs a{d_big, d_ksk, d_sm, in_dim, out_size, p.ks_base_log, p.ks_level, count};
+    dim3 grid((out_size + KS_COLS - 1) / KS_COLS, (count + KS_S - 1) / KS_S, (in_dim + KS_IC - 1) / KS_IC);
+    const size_t lds = (size_t)KS_IC * p.ks_level * KS_S;
+    hipLaunchKernelGGL(keyswitch_kernel, grid, dim3(KS_COLS), lds, stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx, uint64_t* d_big,
+                                uint32_t count) {
+    if (!d_fbsk) return fail("keys not loaded");
+    if (n_luts == 0) return fail("no lookup table uploaded");
+    BlindRotateArgs a{d_sm, d_lut_idx, d_luts, d_fbsk, d_big, p.n, p.pbs_base_log, count};
+    void* args[] = {(void*)&a};
+    HIP_TRY(hipLaunchKernel(variant->rotate_fn, dim3(count), dim3(variant->threads), args,
+                            variant->lds_bytes, stream));
+    return 0;
+}
+
+int Engine::ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint64_t* d_big_out,
+                       uint32_t count) {
+    if (use()) return 1;
+    if (count == 0) return 0;
+    const size_t small = (size_t)p.n + 1;
+    if (ensure((void**)&d_small, &cap_small, count * small * 8)) return 1;
+    HIP_TRY(hipEventRecord(ev[0], stream));
+    if (launch_keyswitch(d_big_in, d_small, count)) return 1;
+    HIP_TRY(hipEventRecord(ev[1], stream));
+    if (launch_blind_rotate(d_small, d_lut_idx, d_big_out, count)) return 1;
+    HIP_TRY(hipEventRecord(ev[2], stream));
+    return 0;
+}
+
+int Engine::check_lut_idx(const uint32_t* lut_idx, uint32_t count) const {
+    if (n_luts == 0) return fail("no lookup table uploaded");
+    if (lut_idx)
+        for (uint32_t i = 0; i < count; i++)
+            if (lut_idx[i] >= n_luts) return fail("lut_idx out of range");
+    return 0;
+}
+
+int Engine::ks_pbs_host(const uint64_t* in, const uint32_t* lut_idx, uint64_t* out, uint32_t count) {
+    if (use()) return 1;
+    if (count == 0) return 0;
+    if (check_lut_idx(lut_idx, count)) return 1;
+    if (ensure_batch(count)) return 1;
+    const size_t big = (size_t)p.k * p.N + 1;
+    HIP_TRY(hipMemcpyAsync(d_in, in, count * big * 8, hipMemcpyHostToDevice, stream));
+    if (lut_idx) HIP_TRY(hipMemcpyAsync(d_idx, lut_idx, (size_t)count * 4, hipMemcpyHostToDevice, stream));
+    if (ks_pbs_dev(d_in, lut_idx ? d_idx : nullptr, d_out, count)) return 1;
+    HIP_TRY(hipMemcpyAsync(out, d_out, count * big * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int Engine::keyswitch_host(const uint64_t* in, uint64_t* out_small, uint32_t count) {
+    if (use()) return 1;
+    if (count == 0) return 0;
+    if (ensure_batch(count)) return 1;
+    const size_t big = (size_t)p.k * p.N + 1, small = (size_t)p.n + 1;
+    HIP_TRY(hipMemcpyAsync(d_in, in, count * big * 8, hipMemcpyHostToDevice, stream));
+    if (launch_keyswitch(d_in, d_small, count)) return 1;
+    HIP_TRY(hipMemcpyAsync(out_small, d_small, count * small * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int Engine::pbs_host(const uint64_t* in_small, const uint32_t* lut_idx, uint64_t* out, uint32_t count) {
+    if (use()) return 1;
+    if (count == 0) return 0;
+    if (check_lut_idx(lut_idx, count)) return 1;
+    if (ensure_batch(count)) return 1;
+    const size_t big = (size_t)p.k * p.N + 1, small = (size_t)p.n + 1;
+    HIP_TRY(hipMemcpyAsync(d_small, in_small, count * small * 8, hipMemcpyHostToDevice, stream));
+    if (lut_idx) HIP_TRY(hipMemcpyAsync(d_idx, lut_idx, (size_t)count * 4, hipMemcpyHostToDevice, stream));
+    if (launch_blind_rotate(d_small, lut_idx ? d_idx : nullptr, d_out, count)) return 1;
+    HIP_TRY(hipMemcpyAsync(out, d_out, count * big * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int Engine::lincomb_dev(const uint64_t* d_pool_, const uint32_t* d_off, const uint32_t* d_src,
+                        const int32_t* d_coeff, const uint64_t* d_cst, uint64_t* d_o, uint32_t jobs) {
+    if (jobs == 0) return 0;
+    LincombArgs a{d_pool_, d_off, d_src, d_coeff, d_cst, d_o, p.k * p.N + 1, jobs};
+    hipLaunchKernelGGL(lincomb_kernel, dim3(jobs), dim3(256), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int Engine::lincomb_host(const uint64_t* pool, uint32_t pool_count, const uint32_t* off,
+                         const uint32_t* src, const int32_t* coeff, const uint64_t* cst,
+                         uint64_t* out, uint32_t jobs) {
+    if (use()) return 1;
+    if (jobs == 0) return 0;
+    const size_t big = (size_t)p.k * p.N + 1;
+    const uint32_t terms = off[jobs];
+    for (uint32_t t = 0; t < terms; t++)
+        if (src[t] >= pool_count) return fail("lincomb source index out of range");
+    if (ensure((void**)&d_pool, &cap_pool, (size_t)pool_count * big * 8)) return 1;
+    if (ensure((void**)&d_out, &cap_out, (size_t)jobs * big * 8)) return 1;
+    // meta: off | src | coeff | cst (8-byte aligned)
+    const size_t o_off = 0, o_src = o_off + ((size_t)(jobs + 1) * 4 + 7) / 8 * 8;
+    const size_t o_coeff = o_src + ((size_t)terms * 4 + 7) / 8 * 8;
+    const size_t o_cst = o_coeff + ((size_t)terms * 4 + 7) / 8 * 8;
+    const size_t meta_bytes = o_cst + (size_t)jobs * 8;
+    if (ensure((void**)&d_meta, &cap_meta, meta_bytes)) return 1;
+    unsigned char* m = reinterpret_cast<unsigned char*>(d_meta);
+    HIP_TRY(hipMemcpyAsync(d_pool, pool, (size_t)pool_count * big * 8, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(m + o_off, off, (size_t)(jobs + 1) * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(m + o_src, src, (size_t)terms * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(m + o_coeff, coeff, (size_t)terms * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(m + o_cst, cst, (size_t)jobs * 8, hipMemcpyHostToDevice, stream));
+    if (lincomb_dev(d_pool, (const uint32_t*)(m + o_off), (const uint32_t*)(m + o_src),
+                    (const int32_t*)(m + o_coeff), (const uint64_t*)(m + o_cst), d_out, jobs))
+        return 1;
+    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)jobs * big * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int Engine::last_kernel_ms(float ms[2]) {
+    if (use()) return 1;
+    HIP_TRY(hipEventSynchronize(ev[2]));
+    HIP_TRY(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms[1], ev[1], ev[2]));
+    return 0;
+}
+
+int Engine::synchronize() {
+    if (use()) return 1;
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
+}  // namespace fhe

@@ -1,0 +1,291 @@
+// negacyclic_fft.hip.h -- in-register / LDS-exchanged complex FFT of size P = N/2 for gfx950.
+//
+// Replaces the reference's f64 negacyclic transform
+//   tfhe/src/core_crypto/fft_impl/fft64/math/fft/mod.rs:378-405,487-557 (forward_as_integer /
+//   forward_as_torus / add_backward_in_place_as_torus), conversions :197-304, twisties :58-69,
+// and the un-vendored concrete-fft 0.3.0 Plan::fwd / Plan::inv it calls.
+//
+// Design (MI355X-first, not a translation):
+//  * one polynomial is transformed by a "group" of T = P/R threads, each holding R complex points
+//    in VGPRs (f64 VALU is the binding unit on CDNA4: 16 FMA lanes/clk/SIMD);
+//  * decimation-in-frequency, in place: pass s does radix-r_s butterflies fully in registers, then
+//    the points are exchanged through LDS (split re/im planes, 8-byte accesses).  Output stays in
+//    the scrambled "last-pass" order -- the Fourier-domain key is stored in exactly that order
+//    (see bsk_convert_kernel), so no reordering pass ever runs; the inverse walks the passes back;
+//  * all twiddles are per-thread constants computed once per kernel (sincospi) and kept in VGPRs
+//    for the whole 742-step blind rotation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fhe {
+
+struct cplx {
+    double re, im;
+};
+
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+    cplx r;
+    r.re = a.re * b.re - a.im * b.im;
+    r.im = a.re * b.im + a.im * b.re;
+    return r;
+}
+__device__ __forceinline__ cplx cmul_conj(cplx a, cplx b) {  // a * conj(b)
+    cplx r;
+    r.re = a.re * b.re + a.im * b.im;
+    r.im = a.im * b.re - a.re * b.im;
+    return r;
+}
+
+// exp(-2*pi*i * j / 16), j = 0..15 (forward sign)
+__device__ constexpr double kCos16[16] = {
+    1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173,
+    0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848,
+    -1.0, -0.92387953251128673848, -0.70710678118654752440, -0.38268343236508977173,
+    0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848};
+__device__ constexpr double kSin16[16] = {
+    0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848,
+    1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173,
+    0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848,
+    -1.0, -0.92387953251128673848, -0.70710678118654752440, -0.38268343236508977173};
+
+// multiply by exp(-+ 2*pi*i * j / len) with len in {2,4,8,16}; j, len are compile-time after
+// unrolling, so the branches fold away.
+template <bool INV>
+__device__ __forceinline__ cplx mul_unit_root(cplx d, int j, int len) {
+    const int e = (j * 16) / len;  // exponent in 16ths of a turn
+    cplx r;
+    if (e == 0) return d;
+    if (e == 4) {  // forward: * (-i) ; inverse: * (+i)
+        if (!INV) { r.re = d.im; r.im = -d.re; } else { r.re = -d.im; r.im = d.re; }
+        return r;
+    }
+    if (e == 8) { r.re = -d.re; r.im = -d.im; return r; }
+    if (e == 12) {
+        if (!INV) { r.re = -d.im; r.im = d.re; } else { r.re = d.im; r.im = -d.re; }
+        return r;
+    }
+    const double c = kCos16[e];
+    const double s = INV ? kSin16[e] : -kSin16[e];
+    if (e == 2 || e == 6 || e == 10 || e == 14) {  // |c| == |s| == sqrt(1/2): 2 mul + 2 add
+        const double h = 0.70710678118654752440;
+        const double sc = c > 0 ? 1.0 : -1.0, ss = s > 0 ? 1.0 : -1.0;
+        // (re + i im) * h * (sc + i ss)
+        r.re = h * (sc * d.re - ss * d.im);
+        r.im = h * (ss * d.re + sc * d.im);
+        return r;
+    }
+    r.re = d.re * c - d.im * s;
+    r.im = d.re * s + d.im * c;
+    return r;
+}
+
+__host__ __device__ constexpr int bitrev(int x, int bits) {
+    int r = 0;
+    for (int b = 0; b < bits; b++)
+        if (x & (1 << b)) r |= 1 << (bits - 1 - b);
+    return r;
+}
+__host__ __device__ constexpr int ilog2c(int x) {
+    int l = 0;
+    while ((1 << l) < x) l++;
+    return l;
+}
+
+// Size-RR DFT on registers x[0..RR), natural order in and out.  y[q] = sum_m x[m] e^{-+2 pi i m q / RR}.
+template <int RR, bool INV>
+__device__ __forceinline__ void small_dft(cplx* x) {
+    if (RR == 1) return;
+#pragma unroll
+    for (int len = RR; len >= 2; len >>= 1) {
+        const int half = len / 2;
+#pragma unroll
+        for (int s = 0; s < RR; s += len) {
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                cplx a = x[s + j], b = x[s + j + half];
+                cplx u, d;
+                u.re = a.re + b.re; u.im = a.im + b.im;
+                d.re = a.re - b.re; d.im = a.im - b.im;
+                x[s + j] = u;
+                x[s + j + half] = mul_unit_root<INV>(d, j, len);
+            }
+        }
+    }
+    // bit-reversal permutation (pure register renaming after unrolling)
+    constexpr int LB = ilog2c(RR);
+    cplx y[RR];
+#pragma unroll
+    for (int q = 0; q < RR; q++) y[q] = x[bitrev(q, LB)];
+#pragma unroll
+    for (int q = 0; q < RR; q++) x[q] = y[q];
+}
+
+// Compile-time description of the pass structure for P points with R per thread.
+template <int LP, int LR>
+struct FftPlan {
+    static constexpr int LOGP = LP;
+    static constexpr int LOGR = LR;
+    static constexpr int P = 1 << LOGP;
+    static constexpr int R = 1 << LOGR;
+    static constexpr int T = P / R;                         // threads per polynomial
+    static constexpr int FULL = LOGP / LOGR;                // passes of radix R
+    static constexpr int LOGLAST = LOGP - FULL * LOGR;      // log2 of the trailing radix (0 = none)
+    static constexpr int NP = FULL + (LOGLAST ? 1 : 0);     // number of passes
+    static constexpr int NTW = NP - 1;                      // passes that carry inter-pass twiddles
+    __host__ __device__ static constexpr int log_radix(int s) { return s < FULL ? LOGR : LOGLAST; }
+    // log2 of sub-transform size at the start of pass s
+    __host__ __device__ static constexpr int log_S(int s) { return LOGP - (s < FULL ? s : FULL) * LOGR; }
+};
+
+// LDS slot swizzle hook (8-byte slots).  Identity for now.
+__device__ __forceinline__ int lds_slot(int a) { return a; }
+
+// Element address (in points) handled by thread tau, group gi, butterfly input m in pass s.
+template <class PL>
+__device__ __forceinline__ int pass_addr(int s, int tau, int gi, int m) {
+    const int lr = PL::log_radix(s);
+    const int lS = PL::log_S(s);
+    const int lS1 = lS - lr;                 // log2 S_{s+1}
+    const int pi = tau + PL::T * gi;         // (Q, t') pair index
+    const int Q = pi >> lS1;
+    const int tp = pi & ((1 << lS1) - 1);
+    return (Q << lS) + (m << lS1) + tp;
+}
+
+// Per-thread constants of one polynomial group.
+template <class PL>
+struct FftConsts {
+    cplx tw[PL::NTW > 0 ? PL::NTW : 1][PL::R];  // tw[s][q] = exp(-2 pi i q t' / S_s); tw[s][0] = 1 unused
+};
+
+template <class PL>
+__device__ __forceinline__ void fft_init_consts(FftConsts<PL>& c, int tau) {
+#pragma unroll
+    for (int s = 0; s < PL::NTW; s++) {
+        const int lS = PL::log_S(s);
+        const int lS1 = lS - PL::LOGR;
+        const int tp = tau & ((1 << lS1) - 1);
+#pragma unroll
+        for (int q = 0; q < PL::R; q++) {
+            double sn, cs;
+            // angle = -2*pi*q*tp / S_s  ->  sincospi(-2*q*tp/S_s)
+            sincospi(-2.0 * (double)(q * tp) / (double)(1 << lS), &sn, &cs);
+            c.tw[s][q].re = cs;
+            c.tw[s][q].im = sn;
+        }
+    }
+}
+
+// Forward transform.  In: x[m] = point (tau + T*m) of the (already twisted) input.
+// Out: x[rho] in last-pass layout.  `re`/`im` are this group's LDS planes (P doubles each).
+template <class PL>
+__device__ __forceinline__ void fft_forward(cplx* x, const FftConsts<PL>& c, double* re, double* im,
+                                            int tau) {
+    constexpr int R = PL::R;
+#pragma unroll
+    for (int s = 0; s < PL::NP; s++) {
+        const int lr = PL::log_radix(s);
+        const int rr = 1 << lr;
+        const int groups = R / rr;
+        if (s > 0) {
+            __syncthreads();
+#pragma unroll
+            for (int gi = 0; gi < groups; gi++)
+#pragma unroll
+                for (int m = 0; m < rr; m++) {
+                    const int a = lds_slot(pass_addr<PL>(s, tau, gi, m));
+                    x[gi * rr + m].re = re[a];
+                    x[gi * rr + m].im = im[a];
+                }
+        }
+        if (lr == PL::LOGR) {
+            small_dft<R, false>(x);
+        } else {
+#pragma unroll
+            for (int gi = 0; gi < groups; gi++) small_dft<(1 << PL::LOGLAST), false>(x + gi * rr);
+        }
+        if (s < PL::NTW) {
+#pragma unroll
+            for (int q = 1; q < R; q++) x[q] = cmul(x[q], c.tw[s][q]);
+        }
+        if (s + 1 < PL::NP) {
+#pragma unroll
+            for (int gi = 0; gi < groups; gi++)
+#pragma unroll
+                for (int m = 0; m < rr; m++) {
+                    const int a = lds_slot(pass_addr<PL>(s, tau, gi, m));
+                    re[a] = x[gi * rr + m].re;
+                    im[a] = x[gi * rr + m].im;
+                }
+        }
+    }
+}
+
+// Inverse transform (unscaled).  In: x[rho] in last-pass layout.  Out: x[m] = point (tau + T*m).
+template <class PL>
+__device__ __forceinline__ void fft_inverse(cplx* x, const FftConsts<PL>& c, double* re, double* im,
+                                            int tau) {
+    constexpr int R = PL::R;
+#pragma unroll
+    for (int s = PL::NP - 1; s >= 0; s--) {
+        const int lr = PL::log_radix(s);
+        const int rr = 1 << lr;
+        const int groups = R / rr;
+        if (s + 1 < PL::NP) {
+            __syncthreads();
+#pragma unroll
+            for (int gi = 0; gi < groups; gi++)
+#pragma unroll
+                for (int m = 0; m < rr; m++) {
+                    const int a = lds_slot(pass_addr<PL>(s, tau, gi, m));
+                    x[gi * rr + m].re = re[a];
+                    x[gi * rr + m].im = im[a];
+                }
+        }
+        if (s < PL::NTW) {
+#pragma unroll
+            for (int q = 1; q < R; q++) x[q] = cmul_conj(x[q], c.tw[s][q]);
+        }
+        if (lr == PL::LOGR) {
+            small_dft<R, true>(x);
+        } else {
+#pragma unroll
+            for (int gi = 0; gi < groups; gi++) small_dft<(1 << PL::LOGLAST), true>(x + gi * rr);
+        }
+        if (s > 0) {
+#pragma unroll
+            for (int gi = 0; gi < groups; gi++)
+#pragma unroll
+                for (int m = 0; m < rr; m++) {
+                    const int a = lds_slot(pass_addr<PL>(s, tau, gi, m));
+                    re[a] = x[gi * rr + m].re;
+                    im[a] = x[gi * rr + m].im;
+                }
+        }
+    }
+}
+
+// ---- integer <-> f64 conversions -------------------------------------------------------------
+
+// torus f64 -> u64: reference commons/math/torus/mod.rs:72-78 (from_torus).  rint() (ties-to-even)
+// stands in for Rust's round() (ties away); they differ only for exact .5 inputs, by one ulp of
+// the 2^-64 grid, far below the FFT error the reference tolerates (fft/tests.rs:40-46).
+__device__ __forceinline__ uint64_t from_torus(double x) {
+    double fr = x - rint(x);
+    double y = rint(fr * 18446744073709551616.0);
+    double h = floor(y * 2.3283064365386963e-10);         // y / 2^32
+    double l = fma(h, -4294967296.0, y);                  // exact, in [0, 2^32)
+    uint32_t hi = (uint32_t)(int32_t)h;                   // v_cvt_i32_f64 (saturating)
+    uint32_t lo = (uint32_t)l;                            // v_cvt_u32_f64
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// signed i64 -> f64 (exact for |v| < 2^53, otherwise correctly rounded via two-part sum)
+__device__ __forceinline__ double i64_to_f64(uint64_t v) {
+    int32_t hi = (int32_t)(v >> 32);
+    uint32_t lo = (uint32_t)v;
+    return fma((double)hi, 4294967296.0, (double)lo);
+}
+
+}  // namespace fhe

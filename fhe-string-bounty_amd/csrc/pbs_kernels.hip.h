@@ -1,0 +1,282 @@
+// pbs_kernels.hip.h -- hand-written gfx950 kernels for the programmable bootstrap.
+//
+//   bsk_convert_kernel   standard-domain bootstrapping key -> Fourier domain, in the FFT's own
+//                        scrambled order.  Replaces par_convert_standard_lwe_bootstrap_key_to_fourier
+//                        (core_crypto/algorithms/lwe_bootstrap_key_conversion.rs:99-152,
+//                         fft64/math/fft/mod.rs:719-764).
+//   blind_rotate_kernel  modulus switch + LUT rotation + n CMUX steps (rotate/subtract, signed
+//                        decomposition, forward FFTs, Fourier-domain multiply-accumulate against
+//                        the GGSW, inverse FFTs, torus rounding) + sample extraction, one LWE per
+//                        workgroup.  Replaces FourierLweBootstrapKeyView::{blind_rotate_assign,
+//                        bootstrap} (fft64/crypto/bootstrap.rs:242-364), add_external_product_assign
+//                        (fft64/crypto/ggsw.rs:477-598), fast_pbs_modulus_switch
+//                        (fft_impl/common.rs:26-43), the monomial rotations
+//                        (algorithms/polynomial_algorithms.rs:315-354,425-490) and
+//                        extract_lwe_sample_from_glwe_ciphertext (glwe_sample_extraction.rs:91-147).
+//
+// Data layout in HBM:
+//   small LWE batch  [B][n+1] u64 (mask then body)            entities/lwe_ciphertext.rs:598-625
+//   LUTs             [n_luts][(k+1)][N] u64                   entities/glwe_ciphertext.rs:210-222
+//   Fourier BSK      [n][level idx][row][col][rho][tau] c64   (rho = register slot, tau = thread:
+//                    one 16-byte element per lane per load -> fully coalesced dwordx4 streams)
+//   big LWE batch    [B][kN+1] u64
+#pragma once
+#include "negacyclic_fft.hip.h"
+
+namespace fhe {
+
+struct BlindRotateArgs {
+    const uint64_t* lwe_small;   // [B][n+1]
+    const uint32_t* lut_idx;     // [B] or nullptr
+    const uint64_t* luts;        // [n_luts][(k+1)N]
+    const double* fbsk;          // Fourier BSK (see layout above)
+    uint64_t* lwe_out;           // [B][kN+1]
+    uint32_t n;                  // small LWE dimension
+    uint32_t base_log;           // PBS decomposition base log
+    uint32_t batch;
+};
+
+// ((x >> (63 - bL)) + 1) >> 1 masked to bL bits == closest_representable(x) >> (64 - bL)
+// (commons/math/decomposition/decomposer.rs:98-118 + fft64/math/decomposition.rs:33-35); bL <= 31.
+__device__ __forceinline__ uint32_t decomp_init_state(uint64_t x, uint32_t bL) {
+    uint32_t t = (uint32_t)(x >> (63 - bL));
+    return ((t + 1u) >> 1) & ((1u << bL) - 1u);
+}
+// commons/math/decomposition/iter.rs:120-127 on a 32-bit state; returns the signed digit.
+__device__ __forceinline__ int32_t decomp_next_digit(uint32_t& state, uint32_t base_log) {
+    const uint32_t mask = (1u << base_log) - 1u;
+    uint32_t res = state & mask;
+    state >>= base_log;
+    uint32_t carry = ((res - 1u) | state) & res;
+    carry >>= base_log - 1;
+    state += carry;
+    return (int32_t)(res - (carry << base_log));
+}
+// fft_impl/common.rs:26-43 (offset 0, lut_count_log 0): result in [0, 2N]
+__device__ __forceinline__ uint32_t modulus_switch(uint64_t x, int logN) {
+    uint64_t o = x >> (64 - logN - 2);
+    return (uint32_t)((o + 1) >> 1);
+}
+
+template <int LOGN, int LOGR, int K1, int L>
+struct BrCfg {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int P = N / 2;
+    using PL = FftPlan<LOGN - 1, LOGR>;
+    static constexpr int R = PL::R;
+    static constexpr int T = PL::T;
+    static constexpr int THREADS = K1 * T;
+    // LDS: accumulator copy (rotation gather source) + FFT exchange planes + spectrum broadcast
+    static constexpr size_t LDS_BYTES = (size_t)K1 * N * 8 /*acc*/ + (size_t)K1 * 2 * P * 8 /*x*/ +
+                                        (size_t)K1 * 2 * P * 8 /*F*/;
+};
+
+// ------------------------------------------------------------------------------------------------
+template <int LOGN, int LOGR, int K1, int L>
+__global__ void __launch_bounds__((BrCfg<LOGN, LOGR, K1, L>::THREADS))
+bsk_convert_kernel(const uint64_t* __restrict__ bsk_std, double* __restrict__ fbsk, uint32_t n_polys) {
+    using CFG = BrCfg<LOGN, LOGR, K1, L>;
+    using PL = typename CFG::PL;
+    constexpr int N = CFG::N, P = CFG::P, R = CFG::R, T = CFG::T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int g = threadIdx.x / T, tau = threadIdx.x % T;
+    double* xre = reinterpret_cast<double*>(smem) + (size_t)g * 2 * P;
+    double* xim = xre + P;
+    const uint32_t poly = blockIdx.x * K1 + g;   // K1 polynomials per workgroup
+    const bool active = poly < n_polys;
+    FftConsts<PL> fc;
+    fft_init_consts<PL>(fc, tau);
+    cplx x[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        const int j = tau + T * m;
+        uint64_t a = active ? bsk_std[(size_t)poly * N + j] : 0;
+        uint64_t b = active ? bsk_std[(size_t)poly * N + j + P] : 0;
+        // forward_as_torus: signed value * 2^-64 (fft/mod.rs:197-218)
+        cplx z;
+        z.re = i64_to_f64(a) * 5.421010862427522e-20;
+        z.im = i64_to_f64(b) * 5.421010862427522e-20;
+        double sn, cs;
+        sincospi((double)j / (double)N, &sn, &cs);  // twisty e^{i pi j / N}
+        cplx w; w.re = cs; w.im = sn;
+        x[m] = cmul(z, w);
+    }
+    fft_forward<PL>(x, fc, xre, xim, tau);
+    if (active) {
+        double2* out = reinterpret_cast<double2*>(fbsk) + (size_t)poly * P;
+#pragma unroll
+        for (int rho = 0; rho < R; rho++) out[rho * T + tau] = make_double2(x[rho].re, x[rho].im);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One workgroup = one LWE sample; K1 groups of T threads, group g owns GLWE polynomial g of the
+// accumulator (2R coefficients per thread, in VGPRs for the whole kernel).
+template <int LOGN, int LOGR, int K1, int L>
+__global__ void __launch_bounds__((BrCfg<LOGN, LOGR, K1, L>::THREADS))
+blind_rotate_kernel(BlindRotateArgs args) {
+    using CFG = BrCfg<LOGN, LOGR, K1, L>;
+    using PL = typename CFG::PL;
+    constexpr int N = CFG::N, P = CFG::P, R = CFG::R, T = CFG::T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t* lds_acc = reinterpret_cast<uint64_t*>(smem);                       // [K1][N]
+    double* lds_x = reinterpret_cast<double*>(smem + (size_t)K1 * N * 8);        // [K1][2][P]
+    double* lds_f = lds_x + (size_t)K1 * 2 * P;                                  // [K1][2][P]
+
+    const int g = threadIdx.x / T, tau = threadIdx.x % T;
+    const uint32_t sample = blockIdx.x;
+    const uint32_t n = args.n;
+    const uint64_t* lwe = args.lwe_small + (size_t)sample * (n + 1);
+    const uint64_t* lut = args.luts + (size_t)(args.lut_idx ? args.lut_idx[sample] : 0) * K1 * N;
+    uint64_t* my_acc = lds_acc + (size_t)g * N;
+    double* xre = lds_x + (size_t)g * 2 * P;
+    double* xim = xre + P;
+    const uint32_t bL = args.base_log * L;
+
+    // per-thread constants: inter-pass twiddles, twisties (forward) and conj(twisty)/P (backward)
+    FftConsts<PL> fc;
+    fft_init_consts<PL>(fc, tau);
+    cplx twist[R], untwist[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        double sn, cs;
+        sincospi((double)(tau + T * m) / (double)N, &sn, &cs);
+        twist[m].re = cs; twist[m].im = sn;
+        untwist[m].re = cs * (1.0 / P); untwist[m].im = sn * (1.0 / P);  // used through cmul_conj
+    }
+
+    // acc <- LUT * X^{-ms(body)}   (bootstrap.rs:254-271, polynomial_algorithms.rs:331-353)
+    uint64_t acc_lo[R], acc_hi[R];   // coefficients j = tau + T*m and j + P
+    {
+        const uint32_t d = modulus_switch(lwe[n], LOGN);
+        const uint32_t rem = d & (N - 1);
+        const bool odd = (d >> LOGN) & 1;
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t j = tau + T * m + h * P;
+                const uint32_t src = (j + rem) & (N - 1);       // out[j] = +-in[j + rem]
+                const bool neg = ((j + rem) >= (uint32_t)N) != odd;
+                uint64_t v = lut[(size_t)g * N + src];
+                v = neg ? (0 - v) : v;
+                if (h == 0) acc_lo[m] = v; else acc_hi[m] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        my_acc[tau + T * m] = acc_lo[m];
+        my_acc[tau + T * m + P] = acc_hi[m];
+    }
+    __syncthreads();
+
+    const double2* fbsk = reinterpret_cast<const double2*>(args.fbsk);
+    constexpr size_t GGSW_ELEMS = (size_t)L * K1 * K1 * P;   // complex elements per GGSW
+
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t a_i = lwe[i];
+        if (a_i == 0) continue;                                  // bootstrap.rs:281 (block-uniform)
+        const uint32_t d = modulus_switch(a_i, LOGN);
+        const uint32_t rem = d & (N - 1);
+        const bool odd = (d >> LOGN) & 1;
+
+        // ct1 = acc * X^d - acc  (polynomial_algorithms.rs:463-489), then decomposition state
+        uint32_t st_lo[R], st_hi[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t j = tau + T * m + h * P;
+                const uint32_t src = (j - rem) & (N - 1);        // (acc*X^d)[j] = +-acc[j - rem]
+                const bool neg = (j < rem) != odd;
+                uint64_t v = my_acc[src];
+                v = neg ? (0 - v) : v;
+                const uint64_t own = h == 0 ? acc_lo[m] : acc_hi[m];
+                const uint32_t st = decomp_init_state(v - own, bL);
+                if (h == 0) st_lo[m] = st; else st_hi[m] = st;
+            }
+        }
+
+        cplx outf[R];
+#pragma unroll
+        for (int it = 0; it < L; it++) {
+            const int lvl_idx = L - 1 - it;                      // ggsw.rs:524 (levels reversed)
+            cplx x[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                cplx z;
+                z.re = (double)decomp_next_digit(st_lo[m], args.base_log);
+                z.im = (double)decomp_next_digit(st_hi[m], args.base_log);
+                x[m] = cmul(z, twist[m]);                        // fft/mod.rs:220-239
+            }
+            fft_forward<PL>(x, fc, xre, xim, tau);
+            // publish this row's spectrum
+            if (it > 0) __syncthreads();                         // previous level's readers done
+            {
+                double* fre = lds_f + (size_t)g * 2 * P;
+                double* fim = fre + P;
+#pragma unroll
+                for (int rho = 0; rho < R; rho++) {
+                    fre[rho * T + tau] = x[rho].re;
+                    fim[rho * T + tau] = x[rho].im;
+                }
+            }
+            __syncthreads();
+            // outf[col = g] (+)= sum_row FBSK[i][lvl][row][g] * F[row]   (ggsw.rs:616-697)
+            const double2* bk = fbsk + (size_t)i * GGSW_ELEMS + (size_t)lvl_idx * K1 * K1 * P;
+#pragma unroll
+            for (int row = 0; row < K1; row++) {
+                const double* fre = lds_f + (size_t)row * 2 * P;
+                const double* fim = fre + P;
+                const double2* b = bk + ((size_t)row * K1 + g) * P;
+#pragma unroll
+                for (int rho = 0; rho < R; rho++) {
+                    const double2 bv = b[rho * T + tau];
+                    cplx f;
+                    f.re = fre[rho * T + tau];
+                    f.im = fim[rho * T + tau];
+                    if (it == 0 && row == 0) {
+                        outf[rho].re = bv.x * f.re - bv.y * f.im;
+                        outf[rho].im = bv.x * f.im + bv.y * f.re;
+                    } else {
+                        outf[rho].re = fma(bv.x, f.re, fma(-bv.y, f.im, outf[rho].re));
+                        outf[rho].im = fma(bv.x, f.im, fma(bv.y, f.re, outf[rho].im));
+                    }
+                }
+            }
+        }
+
+        // back to the standard domain and accumulate (fft/mod.rs:285-304, 539-557)
+        fft_inverse<PL>(outf, fc, xre, xim, tau);
+        // every gather of this step's my_acc happened several barriers ago: safe to overwrite
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            cplx t = cmul_conj(outf[m], untwist[m]);
+            acc_lo[m] += from_torus(t.re);
+            acc_hi[m] += from_torus(t.im);
+            my_acc[tau + T * m] = acc_lo[m];
+            my_acc[tau + T * m + P] = acc_hi[m];
+        }
+        __syncthreads();
+    }
+
+    // sample extraction at degree 0 (glwe_sample_extraction.rs:121-146)
+    uint64_t* out = args.lwe_out + (size_t)sample * ((size_t)(K1 - 1) * N + 1);
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t j = tau + T * m + h * P;
+            const uint64_t v = h == 0 ? acc_lo[m] : acc_hi[m];
+            if (g == K1 - 1) {
+                if (j == 0) out[(size_t)(K1 - 1) * N] = v;         // body = B[0]
+            } else {
+                if (j == 0) out[(size_t)g * N] = v;
+                else out[(size_t)g * N + (N - j)] = 0 - v;         // out[t] = -A[N - t]
+            }
+        }
+    }
+}
+
+}  // namespace fhe

@@ -1,0 +1,283 @@
+"""fhestr -- ctypes binding of libfhestr.so (the C ABI in include/fhestr.h).
+
+This is the thin host-side mirror used by tests and bench.py: it marshals numpy arrays and raw
+device pointers into the C ABI and nothing else.  All compute happens in the HIP library; when the
+library or a GPU is missing every call fails loudly -- there is no CPU fallback here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libfhestr.so")
+
+
+class FheError(RuntimeError):
+    pass
+
+
+class _Params(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32), ("k", C.c_uint32), ("N", C.c_uint32),
+        ("pbs_base_log", C.c_uint32), ("pbs_level", C.c_uint32),
+        ("ks_base_log", C.c_uint32), ("ks_level", C.c_uint32),
+        ("msg_mod", C.c_uint32), ("carry_mod", C.c_uint32),
+        ("lwe_std", C.c_double), ("glwe_std", C.c_double),
+    ]
+
+
+@dataclass(frozen=True)
+class Params:
+    """shortint ClassicPBSParameters (reference: tfhe/src/shortint/parameters/mod.rs:61-76)."""
+    n: int
+    k: int
+    N: int
+    pbs_base_log: int
+    pbs_level: int
+    ks_base_log: int
+    ks_level: int
+    msg_mod: int
+    carry_mod: int
+    lwe_std: float
+    glwe_std: float
+    name: str = ""
+
+    @property
+    def big_size(self) -> int:
+        return self.k * self.N + 1
+
+    @property
+    def small_size(self) -> int:
+        return self.n + 1
+
+    @property
+    def glwe_len(self) -> int:
+        return (self.k + 1) * self.N
+
+    @property
+    def delta(self) -> int:
+        return (1 << 63) // (self.msg_mod * self.carry_mod)
+
+    @property
+    def ksk_len(self) -> int:
+        return self.k * self.N * self.ks_level * (self.n + 1)
+
+    @property
+    def bsk_len(self) -> int:
+        return self.n * self.pbs_level * (self.k + 1) ** 2 * self.N
+
+    def c(self) -> _Params:
+        return _Params(self.n, self.k, self.N, self.pbs_base_log, self.pbs_level, self.ks_base_log,
+                       self.ks_level, self.msg_mod, self.carry_mod, self.lwe_std, self.glwe_std)
+
+
+# reference: tfhe/src/shortint/parameters/mod.rs:703-717, :658-672, :613-627
+PARAM_MESSAGE_2_CARRY_2_KS_PBS = Params(742, 1, 2048, 23, 1, 3, 5, 4, 4,
+                                        0.000007069849454709433, 0.00000000000000029403601535432533,
+                                        "PARAM_MESSAGE_2_CARRY_2_KS_PBS")
+PARAM_MESSAGE_2_CARRY_1_KS_PBS = Params(742, 2, 1024, 23, 1, 4, 3, 4, 2,
+                                        0.000007069849454709433, 0.00000000000000029403601535432533,
+                                        "PARAM_MESSAGE_2_CARRY_1_KS_PBS")
+PARAM_MESSAGE_1_CARRY_1_KS_PBS = Params(684, 3, 512, 18, 1, 4, 3, 2, 2,
+                                        0.00002043784477291318, 0.0000000000034525330484572114,
+                                        "PARAM_MESSAGE_1_CARRY_1_KS_PBS")
+
+_lib = None
+
+EXPORTS = [
+    "fhe_last_error", "fhe_engine_create", "fhe_engine_destroy", "fhe_engine_params",
+    "fhe_engine_load_keys", "fhe_engine_stream", "fhe_engine_synchronize", "fhe_engine_set_variant",
+    "fhe_lut_generate", "fhe_lut_upload", "fhe_lut_download", "fhe_lut_count",
+    "fhe_keyswitch_batch", "fhe_pbs_batch", "fhe_ks_pbs_batch", "fhe_ks_pbs_batch_dev",
+    "fhe_lwe_lincomb_batch", "fhe_last_kernel_ms",
+]
+
+
+def lib() -> C.CDLL:
+    """Load libfhestr.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FheError(f"{LIB_PATH} is missing: run `make -C fhe-string-bounty_amd` "
+                       "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+    PP = C.POINTER(_Params)
+    L.fhe_last_error.restype = C.c_char_p
+    L.fhe_last_error.argtypes = []
+    L.fhe_engine_stream.restype = vp
+    L.fhe_engine_stream.argtypes = [vp]
+
+    def sig(name, *args):
+        fn = getattr(L, name)
+        fn.restype = i32
+        fn.argtypes = list(args)
+
+    sig("fhe_engine_create", PP, i32, C.POINTER(vp))
+    sig("fhe_engine_destroy", vp)
+    sig("fhe_engine_params", vp, PP)
+    sig("fhe_engine_load_keys", vp, vp, vp)
+    sig("fhe_engine_synchronize", vp)
+    sig("fhe_engine_set_variant", vp, i32)
+    sig("fhe_lut_generate", vp, vp, C.POINTER(u32), C.POINTER(C.c_uint64))
+    sig("fhe_lut_upload", vp, vp, C.POINTER(u32))
+    sig("fhe_lut_download", vp, u32, vp)
+    sig("fhe_lut_count", vp, C.POINTER(u32))
+    sig("fhe_keyswitch_batch", vp, vp, vp, u32)
+    sig("fhe_pbs_batch", vp, vp, vp, vp, u32)
+    sig("fhe_ks_pbs_batch", vp, vp, vp, vp, u32)
+    sig("fhe_ks_pbs_batch_dev", vp, vp, vp, vp, u32)
+    sig("fhe_lwe_lincomb_batch", vp, vp, u32, vp, vp, vp, vp, vp, u32)
+    sig("fhe_last_kernel_ms", vp, C.POINTER(C.c_float))
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise FheError(lib().fhe_last_error().decode() or "fhestr call failed")
+
+
+def _u64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One GPU's evaluation engine: resident keys + LUTs, batched KS/PBS (mirrors the evaluation
+    half of shortint::ServerKey, tfhe/src/shortint/server_key/mod.rs)."""
+
+    def __init__(self, params: Params, device: int = 0, log2_points: int = 0):
+        self.params = params
+        self._h = C.c_void_p()
+        _check(lib().fhe_engine_create(C.byref(params.c()), device, C.byref(self._h)))
+        if log2_points:
+            _check(lib().fhe_engine_set_variant(self._h, log2_points))
+
+    def close(self):
+        if self._h:
+            lib().fhe_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def stream(self) -> int:
+        return int(lib().fhe_engine_stream(self._h) or 0)
+
+    def synchronize(self):
+        _check(lib().fhe_engine_synchronize(self._h))
+
+    def load_keys(self, bsk_std, ksk):
+        p = self.params
+        bsk_std, ksk = _u64(bsk_std), _u64(ksk)
+        if bsk_std.size != p.bsk_len or ksk.size != p.ksk_len:
+            raise FheError("key size mismatch")
+        _check(lib().fhe_engine_load_keys(self._h, _ptr(bsk_std), _ptr(ksk)))
+
+    # shortint/server_key/mod.rs:383-399
+    def generate_lookup_table(self, f):
+        p = self.params
+        table = np.array([int(f(i)) for i in range(p.msg_mod * p.carry_mod)], dtype=np.uint64)
+        lut_id, deg = C.c_uint32(), C.c_uint64()
+        _check(lib().fhe_lut_generate(self._h, _ptr(table), C.byref(lut_id), C.byref(deg)))
+        return lut_id.value, deg.value
+
+    # shortint/server_key/bivariate_pbs.rs:71-96,125-130
+    def generate_lookup_table_bivariate(self, f, factor=None):
+        p = self.params
+        factor = factor or p.msg_mod
+        return self.generate_lookup_table(
+            lambda x: f((x // factor) % p.msg_mod, (x % factor) % p.msg_mod))
+
+    def upload_lut(self, acc) -> int:
+        acc = _u64(acc)
+        if acc.size != self.params.glwe_len:
+            raise FheError("accumulator size mismatch")
+        lut_id = C.c_uint32()
+        _check(lib().fhe_lut_upload(self._h, _ptr(acc), C.byref(lut_id)))
+        return lut_id.value
+
+    def download_lut(self, lut_id: int) -> np.ndarray:
+        acc = np.zeros(self.params.glwe_len, dtype=np.uint64)
+        _check(lib().fhe_lut_download(self._h, lut_id, _ptr(acc)))
+        return acc
+
+    def keyswitch(self, cts) -> np.ndarray:
+        p = self.params
+        cts = _u64(cts).reshape(-1, p.big_size)
+        out = np.zeros((cts.shape[0], p.small_size), dtype=np.uint64)
+        _check(lib().fhe_keyswitch_batch(self._h, _ptr(cts), _ptr(out), cts.shape[0]))
+        return out
+
+    def _idx(self, lut_idx, count):
+        if lut_idx is None:
+            return None, None
+        idx = np.ascontiguousarray(lut_idx, dtype=np.uint32)
+        if idx.size != count:
+            raise FheError("lut_idx length mismatch")
+        return idx, _ptr(idx)
+
+    def pbs(self, cts_small, lut_idx=None) -> np.ndarray:
+        p = self.params
+        cts_small = _u64(cts_small).reshape(-1, p.small_size)
+        out = np.zeros((cts_small.shape[0], p.big_size), dtype=np.uint64)
+        idx, ip = self._idx(lut_idx, cts_small.shape[0])
+        _check(lib().fhe_pbs_batch(self._h, _ptr(cts_small), ip, _ptr(out), cts_small.shape[0]))
+        return out
+
+    def apply_lookup_table(self, cts, lut_idx=None) -> np.ndarray:
+        """Batched KS -> PBS (shortint/server_key/mod.rs:457-476,783-857)."""
+        p = self.params
+        cts = _u64(cts).reshape(-1, p.big_size)
+        out = np.zeros_like(cts)
+        idx, ip = self._idx(lut_idx, cts.shape[0])
+        _check(lib().fhe_ks_pbs_batch(self._h, _ptr(cts), ip, _ptr(out), cts.shape[0]))
+        return out
+
+    def apply_lookup_table_dev(self, d_in: int, d_lut_idx: int | None, d_out: int, count: int):
+        """Device-pointer variant, asynchronous on the engine stream."""
+        _check(lib().fhe_ks_pbs_batch_dev(self._h, C.c_void_p(d_in),
+                                          C.c_void_p(d_lut_idx) if d_lut_idx else None,
+                                          C.c_void_p(d_out), count))
+
+    def lincomb(self, pool, jobs):
+        """jobs: list of (terms=[(src, coeff), ...], const_body)."""
+        p = self.params
+        pool = _u64(pool).reshape(-1, p.big_size)
+        off = np.zeros(len(jobs) + 1, dtype=np.uint32)
+        src, coeff, cst = [], [], []
+        for j, (terms, c) in enumerate(jobs):
+            for s, a in terms:
+                src.append(s)
+                coeff.append(a)
+            off[j + 1] = len(src)
+            cst.append(c & (2 ** 64 - 1))
+        src = np.array(src + [0], dtype=np.uint32)
+        coeff = np.array(coeff + [0], dtype=np.int32)
+        cst = np.array(cst, dtype=np.uint64)
+        out = np.zeros((len(jobs), p.big_size), dtype=np.uint64)
+        _check(lib().fhe_lwe_lincomb_batch(self._h, _ptr(pool), pool.shape[0], _ptr(off), _ptr(src),
+                                           _ptr(coeff), _ptr(cst), _ptr(out), len(jobs)))
+        return out
+
+    def last_kernel_ms(self):
+        ms = (C.c_float * 2)()
+        _check(lib().fhe_last_kernel_ms(self._h, ms))
+        return float(ms[0]), float(ms[1])

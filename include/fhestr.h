@@ -1,0 +1,103 @@
+/*
+ * fhestr.h -- C ABI of the MI355X-native FheString engine (libfhestr.so).
+ *
+ * Drop-in boundary for the hot path of the reference (tfhe-rs 0.5.0 fork, paths under
+ * /root/reference/tfhe/src): the batched shortint `apply_lookup_table` = LWE keyswitch +
+ * programmable bootstrap, the LWE linear ops around it, the integer-layer comparison loops that
+ * call it, and the FheString operations built from those.  Conventions follow the reference's own
+ * C API (c_api/utils.rs:3-28, c_api/shortint/server_key/pbs.rs:24-85): opaque handles, `int`
+ * return (0 = ok), results through out-pointers, caller-owned flat u64 buffers.
+ *
+ * Ciphertext layouts are the reference's (entities/lwe_ciphertext.rs:598-625,
+ * lwe_keyswitch_key.rs:77-108, lwe_bootstrap_key.rs, glwe_ciphertext.rs:210-222):
+ *   big LWE    [a_0 .. a_{kN-1}, b]          kN+1 u64
+ *   small LWE  [a_0 .. a_{n-1}, b]           n+1 u64
+ *   KSK        [kN][ks_level (level l first)][n+1] u64
+ *   BSK (std)  [n][pbs_level (level 1 first)][k+1 rows][k+1 polys][N] u64
+ *   LUT / accumulator  [k+1][N] u64 (mask polynomials zero)
+ *
+ * Pointers named d_* are device (HBM) pointers on the engine's GPU; all others are host pointers.
+ * An engine is bound to one GPU and one HIP stream; calls on one engine must be serialised by the
+ * caller (the reference keeps its scratch in a thread-local ShortintEngine,
+ * shortint/engine/mod.rs:23-25,184-189 -- here: one engine per host thread / per rank).
+ */
+#ifndef FHESTR_H
+#define FHESTR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* shortint/parameters/mod.rs:61-76 (ClassicPBSParameters; native modulus 2^64, KS->PBS order) */
+typedef struct fhe_params_t {
+    uint32_t n, k, N;
+    uint32_t pbs_base_log, pbs_level;
+    uint32_t ks_base_log, ks_level;
+    uint32_t msg_mod, carry_mod;
+    double lwe_std, glwe_std;
+} fhe_params_t;
+
+typedef struct fhe_engine fhe_engine;
+
+/* Last error message of the calling thread ("" if none). */
+const char *fhe_last_error(void);
+
+/* ---- engine + keys ------------------------------------------------------------------------ */
+/* replaces ServerKey construction (shortint/engine/server_side.rs:54-160), evaluation side only */
+int fhe_engine_create(const fhe_params_t *params, int device, fhe_engine **out);
+int fhe_engine_destroy(fhe_engine *eng);
+int fhe_engine_params(const fhe_engine *eng, fhe_params_t *out);
+/* Upload KSK and standard-domain BSK; the BSK is converted on the GPU to the engine's Fourier
+ * layout (replaces par_convert_standard_lwe_bootstrap_key_to_fourier,
+ * core_crypto/algorithms/lwe_bootstrap_key_conversion.rs:99-152). */
+int fhe_engine_load_keys(fhe_engine *eng, const uint64_t *bsk_std, const uint64_t *ksk);
+/* The engine's HIP stream (hipStream_t) so callers can order their own work against it. */
+void *fhe_engine_stream(fhe_engine *eng);
+int fhe_engine_synchronize(fhe_engine *eng);
+/* Choose the blind-rotation variant: points per thread = 2^log2_points (0 = automatic). */
+int fhe_engine_set_variant(fhe_engine *eng, int log2_points);
+
+/* ---- lookup tables ------------------------------------------------------------------------- */
+/* generate_lookup_table (shortint/server_key/mod.rs:383-399, engine/mod.rs:72-128):
+ * table[i] = f(i), i < msg_mod*carry_mod.  Returns the LUT id and its degree (max f). */
+int fhe_lut_generate(fhe_engine *eng, const uint64_t *table, uint32_t *lut_id, uint64_t *degree);
+/* Upload an already-built accumulator ((k+1)*N u64). */
+int fhe_lut_upload(fhe_engine *eng, const uint64_t *accumulator, uint32_t *lut_id);
+/* Read an accumulator back ((k+1)*N u64). */
+int fhe_lut_download(fhe_engine *eng, uint32_t lut_id, uint64_t *accumulator);
+int fhe_lut_count(const fhe_engine *eng, uint32_t *count);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+/* keyswitch_lwe_ciphertext (core_crypto/algorithms/lwe_keyswitch.rs:96-170), batched. */
+int fhe_keyswitch_batch(fhe_engine *eng, const uint64_t *lwe_big_in, uint64_t *lwe_small_out,
+                        uint32_t count);
+/* programmable_bootstrap_lwe_ciphertext_mem_optimized
+ * (core_crypto/algorithms/lwe_programmable_bootstrapping.rs:1067-1111), batched; lut_idx may be
+ * NULL (LUT 0 for all). */
+int fhe_pbs_batch(fhe_engine *eng, const uint64_t *lwe_small_in, const uint32_t *lut_idx,
+                  uint64_t *lwe_big_out, uint32_t count);
+/* apply_lookup_table / keyswitch_programmable_bootstrap_assign
+ * (shortint/server_key/mod.rs:457-476,783-857), batched, host buffers. */
+int fhe_ks_pbs_batch(fhe_engine *eng, const uint64_t *lwe_big_in, const uint32_t *lut_idx,
+                     uint64_t *lwe_big_out, uint32_t count);
+/* Same with everything resident in HBM; asynchronous on the engine stream. */
+int fhe_ks_pbs_batch_dev(fhe_engine *eng, const uint64_t *d_lwe_big_in, const uint32_t *d_lut_idx,
+                         uint64_t *d_lwe_big_out, uint32_t count);
+/* LWE linear combinations (unchecked_add / scalar_mul / scalar_add / bivariate packing,
+ * shortint/server_key/add.rs:520-524, scalar_mul.rs:206-208, scalar_add.rs:211-218,
+ * bivariate_pbs.rs:167-182): out[j] = sum_{t in [off[j],off[j+1])} coeff[t]*pool[src[t]],
+ * then body += cst[j].  Host buffers. */
+int fhe_lwe_lincomb_batch(fhe_engine *eng, const uint64_t *pool, uint32_t pool_count,
+                          const uint32_t *off, const uint32_t *src, const int32_t *coeff,
+                          const uint64_t *cst, uint64_t *out, uint32_t jobs);
+/* Kernel-only timing of the last fhe_ks_pbs_batch*_ call (HIP events on the engine stream):
+ * ms[0] = keyswitch, ms[1] = blind rotation + sample extraction. Synchronises. */
+int fhe_last_kernel_ms(fhe_engine *eng, float ms[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

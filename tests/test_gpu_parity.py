@@ -1,0 +1,166 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on identical keys and inputs.
+
+Bit-exact where the reference is integer-only (keyswitch, modulus switch, rotation, sample
+extraction, linear ops, LUT generation); decrypt-level plus a torus-distance tolerance where the
+reference itself is f64-FFT based (its own tests assert no more: fft64/math/fft/tests.rs:166-173,
+fft64/crypto/tests.rs:5-13, algorithms/test/lwe_programmable_bootstrapping.rs:152-156)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import gpu_engine, keyset, torus_distance
+
+pytestmark = pytest.mark.gpu
+
+PARAM_SETS = [O.TOY_K1, O.TOY_K2, O.PARAM_MESSAGE_2_CARRY_2_KS_PBS]
+
+
+def _phase_tolerance(p):
+    """Bound on |phase_gpu - phase_oracle| (phase = b - <a, s>, the only quantity two f64
+    implementations can be compared on: one flipped decomposition digit re-randomises the mask
+    coefficients while moving the phase by noise only).
+
+    One f64 negacyclic product is allowed 2^(64 - (52 - digit_bits - log2 N)) per coefficient by the
+    reference (fft/tests.rs:166-173).  A PBS output coefficient sums n*(k+1)*level such products
+    (in quadrature) and the phase sums kN/2 key-selected coefficients (again in quadrature).
+    On top of that, a coefficient sitting on a rounding boundary of closest_representable
+    (decomposer.rs:98-118) may round the other way under a 2^-30 perturbation; each such flip
+    moves the phase by one decomposition granule 2^(64 - base_log*level) times a key coefficient --
+    bounded here by the full rounding-noise budget of the blind rotation."""
+    logN = p.N.bit_length() - 1
+    one = 2.0 ** (64 - (52 - p.pbs_base_log - logN))
+    fft = one * np.sqrt(p.n * p.pbs_level * (p.k + 1)) * np.sqrt(p.k * p.N / 2)
+    granule = 2.0 ** (64 - p.pbs_base_log * p.pbs_level)
+    return fft + granule * np.sqrt(p.n * (p.k * p.N / 2 + 1))
+
+
+def _phases(ks, cts):
+    return np.array([ks.ck.decrypt_plaintext(c) for c in cts], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("params", PARAM_SETS, ids=lambda p: p.name)
+def test_keyswitch_bit_exact(params):
+    ks = keyset(params)
+    eng = gpu_engine(ks)
+    rng = np.random.default_rng(1)
+    B = 37  # ragged: not a multiple of the kernel's sample tile
+    cts = rng.integers(0, 2**64, size=(B, params.big_size), dtype=np.uint64)
+    cts[0, :] = 0
+    cts[1, :-1] = 0  # trivial ciphertext
+    cts[2, :] = 2**64 - 1
+    got = eng.keyswitch(cts)
+    want = np.stack([ks.sk.keyswitch(c) for c in cts])
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("params", PARAM_SETS, ids=lambda p: p.name)
+def test_lut_generation_matches_oracle(params):
+    ks = keyset(params)
+    eng = gpu_engine(ks)
+    M = params.msg_mod * params.carry_mod
+    f = lambda x: (5 * x + 3) % M
+    lut_id, deg = eng.generate_lookup_table(f)
+    want, want_deg = ks.sk.generate_lookup_table(f)
+    assert deg == want_deg
+    assert np.array_equal(eng.download_lut(lut_id), want)
+
+
+@pytest.mark.parametrize("params", PARAM_SETS, ids=lambda p: p.name)
+def test_pbs_zero_mask_bit_exact(params):
+    """a_i == 0 skips every CMUX (bootstrap.rs:281): only modulus switch, LUT rotation and sample
+    extraction run -- all integer, so ciphertext bits must match the oracle exactly."""
+    ks = keyset(params)
+    eng = gpu_engine(ks)
+    M = params.msg_mod * params.carry_mod
+    lut, _ = ks.sk.generate_lookup_table(lambda x: (3 * x + 1) % M)
+    lut_id = eng.upload_lut(lut)
+    rng = np.random.default_rng(2)
+    B = 19
+    small = np.zeros((B, params.small_size), dtype=np.uint64)
+    small[:, -1] = rng.integers(0, 2**64, size=B, dtype=np.uint64)
+    small[0, -1] = 0
+    small[1, -1] = 2**64 - 1          # modulus switch returns 2N
+    small[2, -1] = 2**63
+    got = eng.pbs(small, np.full(B, lut_id, dtype=np.uint32))
+    want = np.stack([ks.sk.pbs(s, lut) for s in small])
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("params", PARAM_SETS, ids=lambda p: p.name)
+def test_ks_pbs_decrypts_and_tracks_oracle(params):
+    ks = keyset(params)
+    eng = gpu_engine(ks)
+    M = params.msg_mod * params.carry_mod
+    f0 = lambda x: x
+    f1 = lambda x: (x * x + 1) % M
+    l0, d0 = ks.sk.generate_lookup_table(f0)
+    l1, d1 = ks.sk.generate_lookup_table(f1)
+    id0, id1 = eng.upload_lut(l0), eng.upload_lut(l1)
+    reps = 3
+    msgs = np.array([m for m in range(M)] * reps)
+    rng = O.Rng(0x5EED0002, 9)
+    cts = ks.ck.encrypt_many(msgs, rng)
+    which = (np.arange(len(msgs)) // M) % 2
+    idx = np.where(which == 0, id0, id1).astype(np.uint32)
+    got = eng.apply_lookup_table(cts, idx)
+    dec = ks.ck.decrypt_many(got)
+    want_clear = np.array([f0(m) if w == 0 else f1(m) for m, w in zip(msgs, which)])
+    assert np.array_equal(dec, want_clear)
+    # phase-level: GPU f64 path vs the oracle's f64 path stay within the FFT tolerance
+    luts = np.stack([l0, l1])
+    want = ks.sk.apply_lookup_table_batch(cts, luts, which.astype(np.uint32))
+    dist = torus_distance(_phases(ks, got), _phases(ks, want))
+    print(f"{params.name}: max phase distance GPU vs oracle-fft = 2^{np.log2(dist.max() + 1):.1f}, "
+          f"tolerance 2^{np.log2(_phase_tolerance(params)):.1f}, delta/2 = 2^{np.log2(params.delta / 2):.0f}")
+    assert dist.max() < _phase_tolerance(params)
+    assert _phase_tolerance(params) < params.delta / 4
+
+
+@pytest.mark.parametrize("params", [O.TOY_K1, O.TOY_K2], ids=lambda p: p.name)
+def test_ks_pbs_tracks_exact_integer_oracle(params):
+    """Against the exact-integer external product (no FFT at all)."""
+    ks = keyset(params)
+    eng = gpu_engine(ks)
+    M = params.msg_mod * params.carry_mod
+    lut, _ = ks.sk.generate_lookup_table(lambda x: (M - 1 - x))
+    lut_id = eng.upload_lut(lut)
+    cts = ks.ck.encrypt_many(range(M), O.Rng(77, 1))
+    got = eng.apply_lookup_table(cts, np.full(M, lut_id, dtype=np.uint32))
+    want = ks.sk.apply_lookup_table_batch(cts, lut, exact=True)
+    assert np.array_equal(ks.ck.decrypt_many(got), ks.ck.decrypt_many(want))
+    dist = torus_distance(_phases(ks, got), _phases(ks, want))
+    print(f"{params.name}: max phase distance GPU vs exact-integer oracle = 2^{np.log2(dist.max() + 1):.1f}")
+    assert dist.max() < _phase_tolerance(params)
+
+
+def test_lincomb_bit_exact():
+    params = O.TOY_K1
+    ks = keyset(params)
+    eng = gpu_engine(ks)
+    rng = np.random.default_rng(3)
+    pool = rng.integers(0, 2**64, size=(11, params.big_size), dtype=np.uint64)
+    jobs = [([(0, 1)], 0), ([(1, 4), (2, 1)], 0), ([(3, -1), (4, 1)], 5 * params.delta),
+            ([], 7 * params.delta), ([(i, i - 5) for i in range(11)], 2**64 - 1)]
+    got = eng.lincomb(pool, jobs)
+    with np.errstate(over="ignore"):
+        for row, (terms, c) in zip(got, jobs):
+            want = np.zeros(params.big_size, dtype=np.uint64)
+            for s, a in terms:
+                want += pool[s] * np.uint64(a % 2**64)
+            want[-1] += np.uint64(c % 2**64)
+            assert np.array_equal(row, want)
+
+
+def test_p22_batch_256_decrypts(p22):
+    """BASELINE.json config 2: 256 independent LWEs, PARAM_MESSAGE_2_CARRY_2, per-LWE LUTs."""
+    eng = gpu_engine(p22)
+    M = 16
+    rng = np.random.default_rng(0x5EED0002)
+    tables = rng.integers(0, M, size=(16, M))
+    ids = [eng.generate_lookup_table(lambda x, t=t: int(t[x]))[0] for t in tables]
+    msgs = rng.integers(0, M, size=256)
+    sel = rng.integers(0, 16, size=256)
+    cts = p22.ck.encrypt_many(msgs, O.Rng(0x5EED0002, 1))
+    got = eng.apply_lookup_table(cts, np.array([ids[s] for s in sel], dtype=np.uint32))
+    dec = p22.ck.decrypt_many(got)
+    assert np.array_equal(dec, tables[sel, msgs])
