@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- PBS/sec of the batched keyswitch + programmable bootstrap on MI355X.
+
+Workload (BASELINE.json configs[1]): B = 256 independent shortint LWE ciphertexts,
+PARAM_MESSAGE_2_CARRY_2_KS_PBS, per-LWE lookup tables, one GPU.  A "step" is one pass of the hot
+path (memset -> keyswitch kernel -> blind-rotate kernel) over that batch with inputs, keys and
+tables already resident in HBM.  With N GPUs every rank runs its own 256-LWE batch on its own
+GPU (independent units, replicated keys, no data-path collective): weak scaling, value = all
+LWEs of all ranks / max-over-ranks time.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "fhe-string-bounty_amd"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+SEED = 0x5EED0002
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="LWEs per step per GPU")
+    ap.add_argument("--log2-points", type=int, default=0, help="blind-rotate variant (0 = default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(P, bsk, ksk, cts, lut_tables, lut_sel):
+    """Time the CPU oracle (a C port of the reference algorithm) on the same batch, all host cores.
+    The ONLY place bench.py touches oracle/ -- as a reported baseline, never as the product."""
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import oracle as O
+    op = O.Params(P.n, P.k, P.N, P.pbs_base_log, P.pbs_level, P.ks_base_log, P.ks_level,
+                  P.msg_mod, P.carry_mod, P.lwe_std, P.glwe_std, P.name)
+    cores = min(os.cpu_count() or 1, 16)
+    L = O.lib()
+    fbsk = np.zeros(bsk.size, dtype=np.float64)
+    L.orc_bsk_to_fourier(C.byref(op.c()), bsk, fbsk)
+    luts = np.zeros((len(lut_tables), op.glwe_len), dtype=np.uint64)
+    for i, t in enumerate(lut_tables):
+        L.orc_fill_accumulator(C.byref(op.c()), np.ascontiguousarray(t, dtype=np.uint64), luts[i])
+    out = np.zeros_like(cts)
+    idx = np.ascontiguousarray(lut_sel, dtype=np.uint32)
+    t0 = time.perf_counter()
+    L.orc_ks_pbs_batch(C.byref(op.c()), ksk, fbsk.ctypes.data_as(C.c_void_p), None, 0, cts,
+                       idx.ctypes.data_as(C.c_void_p), luts, out, cts.shape[0], cores)
+    dt = time.perf_counter() - t0
+    return {"value": cts.shape[0] / dt, "unit": "PBS/s", "cores": cores, "kind": "port",
+            "sample": f"the same {cts.shape[0]}-LWE batch, KS+PBS per LWE, {cores} host threads over LWEs "
+                      f"(oracle/tfhe_oracle.c, gcc -O3; reference publishes 16.6 ms/PBS/core on Xeon 8375C)",
+            "seconds": dt}, out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    import fhestr
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    P = fhestr.PARAM_MESSAGE_2_CARRY_2_KS_PBS
+    B = args.batch
+    M = P.msg_mod * P.carry_mod
+
+    # ---- synthetic workload: keys from a seed, uniform messages, 16 random LUTs ----
+    ck = fhestr.ClientKey(P, SEED)
+    bsk, ksk = ck.gen_server_keys()
+    rng = np.random.default_rng(SEED + rank)
+    tables = rng.integers(0, M, size=(16, M))
+    msgs = rng.integers(0, M, size=B)
+    sel = rng.integers(0, 16, size=B)
+    cts = ck.encrypt(msgs)
+
+    eng = fhestr.Engine(P, local_rank, args.log2_points)
+    eng.load_keys(bsk, ksk)
+    lut_ids = np.array([eng.generate_lookup_table(lambda x, t=t: int(t[x]))[0] for t in tables], dtype=np.uint32)
+    idx = lut_ids[sel]
+
+    d_in = torch.from_numpy(cts.view(np.int64)).cuda()
+    d_idx = torch.from_numpy(idx.view(np.int32)).cuda()
+    d_out = torch.zeros_like(d_in)
+    torch.cuda.synchronize()
+
+    def step():
+        eng.apply_lookup_table_dev(d_in.data_ptr(), d_idx.data_ptr(), d_out.data_ptr(), B)
+
+    def fence():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.kernel_times(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ks_ms, br_ms, calls = eng.kernel_times(reset=True)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+
+    # ---- correctness gate on the timed output: decrypt == LUT(message) for every LWE ----
+    got = d_out.cpu().numpy().view(np.uint64)
+    dec = ck.decrypt(got)
+    verified = bool(np.array_equal(dec, tables[sel, msgs]))
+    if world > 1:
+        v = torch.tensor([1 if verified else 0], device="cuda")
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        verified = bool(v.item())
+
+    if rank == 0:
+        total_pbs = B * world * args.steps
+        value = total_pbs / elapsed
+        # dominant kernel = blind_rotate_kernel.  Algorithmic bytes per LWE (per-LWE streaming model,
+        # SURVEY 8(d) restricted to this kernel): Fourier BSK + LUT + small LWE in + big LWE out.
+        br_bytes = P.bsk_len * 8 + P.glwe_len * 8 + P.small_size * 8 + P.big_size * 8
+        br_avg_ms = br_ms / max(calls, 1)
+        achieved = br_bytes * B / (br_avg_ms * 1e-3) / 1e9
+        pbs_bytes = P.bsk_len * 8 + P.ksk_len * 8 + 2 * P.big_size * 8 + P.glwe_len * 8  # 109,559,824
+        rec = {
+            "metric": "PBS/sec (whole node)", "value": value, "unit": "PBS/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "batched KS+PBS: 256 independent shortint LWE ciphertexts, "
+                                   "PARAM_MESSAGE_2_CARRY_2_KS_PBS, 16 random LUTs, 1xMI355X per rank",
+                       "batch_per_gpu": B, "params": P.name, "parallelism": f"replicated keys x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "blind_rotate_kernel", "avg_launch_ms": br_avg_ms,
+                         "algorithmic_bytes_per_lwe": br_bytes, "lwes_per_launch": B},
+            "kernel_ms": {"keyswitch": ks_ms / max(calls, 1), "blind_rotate": br_avg_ms, "launches": calls},
+            "whole_pbs_hbm_model": {"bytes_per_pbs": pbs_bytes,
+                                    "frac_of_peak": value * pbs_bytes / (world * HBM_PEAK_GBS * 1e9)},
+            "verified_decrypt": verified,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                cb, cpu_out = cpu_baseline(P, bsk, ksk, cts, tables, sel)
+                cb["decrypt_matches_gpu"] = bool(np.array_equal(ck.decrypt(cpu_out), dec))
+                rec["cpu_baseline"] = cb
+            except Exception as e:  # the baseline is informative; never let it kill the GPU number
+                rec["cpu_baseline"] = {"value": None, "unit": "PBS/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not verified:
+        raise SystemExit("decrypt check failed")
+
+
+if __name__ == "__main__":
+    main()

@@ -153,4 +153,11 @@ int fhe_last_kernel_ms(fhe_engine* eng, float ms[2]) {
     API_END
 }
 
+int fhe_kernel_times(fhe_engine* eng, double total_ms[2], uint32_t* calls, int reset) {
+    API_BEGIN
+    CHECK_PTR(eng); CHECK_PTR(total_ms); CHECK_PTR(calls);
+    return eng->impl->kernel_times(total_ms, calls, reset != 0);
+    API_END
+}
+
 }  // extern "C"

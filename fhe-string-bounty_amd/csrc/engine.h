@@ -19,7 +19,9 @@ struct Engine {
     fhe_params_t p{};
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // scratch triple (unused slots of the ring below)
+    std::vector<hipEvent_t> ring;   // 3 events per recorded ks_pbs call
+    size_t ring_used = 0;           // calls recorded since the last reset
     const BrVariant* variant = nullptr;
 
     // resident keys / tables
@@ -57,6 +59,7 @@ struct Engine {
     int lincomb_host(const uint64_t* pool, uint32_t pool_count, const uint32_t* off, const uint32_t* src,
                      const int32_t* coeff, const uint64_t* cst, uint64_t* out, uint32_t jobs);
     int last_kernel_ms(float ms[2]);
+    int kernel_times(double total_ms[2], uint32_t* calls, bool reset);
     int synchronize();
 };
 

@@ -58,7 +58,7 @@ BrVariant make_variant() {
 static const std::vector<BrVariant>& variants() {
     static const std::vector<BrVariant> v = {
         // PARAM_MESSAGE_2_CARRY_2_KS_PBS: N=2048, k=1, l=1  (first entry of a shape = default)
-        make_variant<11, 3, 2, 1>(), make_variant<11, 2, 2, 1>(), make_variant<11, 4, 2, 1>(),
+        make_variant<11, 2, 2, 1>(), make_variant<11, 3, 2, 1>(), make_variant<11, 4, 2, 1>(),
         // N=1024, k=2, l=1 family (PARAM_MESSAGE_2_CARRY_1_KS_PBS ...)
         make_variant<10, 3, 3, 1>(), make_variant<10, 2, 3, 1>(),
         // PARAM_MESSAGE_1_CARRY_1_KS_PBS: N=512, k=3, l=1
@@ -114,6 +114,7 @@ Engine::~Engine() {
     rel(d_ksk); rel(d_fbsk); rel(d_luts); rel(d_in); rel(d_small); rel(d_out); rel(d_idx);
     rel(d_pool); rel(d_meta);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ring) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -252,11 +253,19 @@ int Engine::ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint
     if (count == 0) return 0;
     const size_t small = (size_t)p.n + 1;
     if (ensure((void**)&d_small, &cap_small, count * small * 8)) return 1;
-    HIP_TRY(hipEventRecord(ev[0], stream));
+    // HIP events on the launch stream: per-call kernel durations without host synchronisation
+    constexpr size_t RING = 1024;
+    if (ring.empty()) {
+        ring.resize(RING * 3);
+        for (auto& e : ring) HIP_TRY(hipEventCreate(&e));
+    }
+    hipEvent_t* e3 = &ring[(ring_used % RING) * 3];
+    ring_used++;
+    HIP_TRY(hipEventRecord(e3[0], stream));
     if (launch_keyswitch(d_big_in, d_small, count)) return 1;
-    HIP_TRY(hipEventRecord(ev[1], stream));
+    HIP_TRY(hipEventRecord(e3[1], stream));
     if (launch_blind_rotate(d_small, d_lut_idx, d_big_out, count)) return 1;
-    HIP_TRY(hipEventRecord(ev[2], stream));
+    HIP_TRY(hipEventRecord(e3[2], stream));
     return 0;
 }
 
@@ -350,9 +359,29 @@ int Engine::lincomb_host(const uint64_t* pool, uint32_t pool_count, const uint32
 
 int Engine::last_kernel_ms(float ms[2]) {
     if (use()) return 1;
-    HIP_TRY(hipEventSynchronize(ev[2]));
-    HIP_TRY(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
-    HIP_TRY(hipEventElapsedTime(&ms[1], ev[1], ev[2]));
+    if (ring_used == 0) return fail("no ks_pbs call recorded");
+    hipEvent_t* e3 = &ring[((ring_used - 1) % 1024) * 3];
+    HIP_TRY(hipEventSynchronize(e3[2]));
+    HIP_TRY(hipEventElapsedTime(&ms[0], e3[0], e3[1]));
+    HIP_TRY(hipEventElapsedTime(&ms[1], e3[1], e3[2]));
+    return 0;
+}
+
+int Engine::kernel_times(double total_ms[2], uint32_t* calls, bool reset) {
+    if (use()) return 1;
+    HIP_TRY(hipStreamSynchronize(stream));
+    const size_t nrec = ring_used < 1024 ? ring_used : 1024;
+    total_ms[0] = total_ms[1] = 0.0;
+    for (size_t c = 0; c < nrec; c++) {
+        hipEvent_t* e3 = &ring[((ring_used - 1 - c) % 1024) * 3];
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, e3[0], e3[1]));
+        HIP_TRY(hipEventElapsedTime(&b, e3[1], e3[2]));
+        total_ms[0] += a;
+        total_ms[1] += b;
+    }
+    *calls = (uint32_t)nrec;
+    if (reset) ring_used = 0;
     return 0;
 }
 

@@ -93,7 +93,9 @@ EXPORTS = [
     "fhe_engine_load_keys", "fhe_engine_stream", "fhe_engine_synchronize", "fhe_engine_set_variant",
     "fhe_lut_generate", "fhe_lut_upload", "fhe_lut_download", "fhe_lut_count",
     "fhe_keyswitch_batch", "fhe_pbs_batch", "fhe_ks_pbs_batch", "fhe_ks_pbs_batch_dev",
-    "fhe_lwe_lincomb_batch", "fhe_last_kernel_ms",
+    "fhe_lwe_lincomb_batch", "fhe_last_kernel_ms", "fhe_kernel_times",
+    "fhe_params_ksk_len", "fhe_params_bsk_len", "fhe_client_key_create", "fhe_client_key_destroy",
+    "fhe_client_encrypt", "fhe_client_decrypt", "fhe_client_gen_server_keys", "fhe_client_secret_keys",
 ]
 
 
@@ -134,6 +136,16 @@ def lib() -> C.CDLL:
     sig("fhe_ks_pbs_batch_dev", vp, vp, vp, vp, u32)
     sig("fhe_lwe_lincomb_batch", vp, vp, u32, vp, vp, vp, vp, vp, u32)
     sig("fhe_last_kernel_ms", vp, C.POINTER(C.c_float))
+    sig("fhe_kernel_times", vp, C.POINTER(C.c_double), C.POINTER(u32), i32)
+    sig("fhe_client_key_create", PP, C.c_uint64, C.POINTER(vp))
+    sig("fhe_client_key_destroy", vp)
+    sig("fhe_client_encrypt", vp, vp, u32, vp)
+    sig("fhe_client_decrypt", vp, vp, u32, vp)
+    sig("fhe_client_gen_server_keys", vp, vp, vp, i32)
+    sig("fhe_client_secret_keys", vp, vp, vp)
+    for name in ("fhe_params_ksk_len", "fhe_params_bsk_len"):
+        getattr(L, name).restype = C.c_size_t
+        getattr(L, name).argtypes = [PP]
     _lib = L
     return L
 
@@ -281,3 +293,58 @@ class Engine:
         ms = (C.c_float * 2)()
         _check(lib().fhe_last_kernel_ms(self._h, ms))
         return float(ms[0]), float(ms[1])
+
+    def kernel_times(self, reset=True):
+        """(keyswitch_ms_total, blind_rotate_ms_total, calls) since the last reset (HIP events)."""
+        ms = (C.c_double * 2)()
+        calls = C.c_uint32()
+        _check(lib().fhe_kernel_times(self._h, ms, C.byref(calls), 1 if reset else 0))
+        return float(ms[0]), float(ms[1]), int(calls.value)
+
+
+class ClientKey:
+    """Client side (CPU): mirrors shortint::ClientKey (tfhe/src/shortint/client_key/mod.rs)."""
+
+    def __init__(self, params: Params, seed: int):
+        self.params = params
+        self._h = C.c_void_p()
+        _check(lib().fhe_client_key_create(C.byref(params.c()), seed, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().fhe_client_key_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encrypt(self, msgs) -> np.ndarray:
+        msgs = _u64(np.atleast_1d(msgs))
+        cts = np.zeros((msgs.size, self.params.big_size), dtype=np.uint64)
+        _check(lib().fhe_client_encrypt(self._h, _ptr(msgs), msgs.size, _ptr(cts)))
+        return cts
+
+    def decrypt(self, cts) -> np.ndarray:
+        """message-and-carry value of every ciphertext."""
+        cts = _u64(cts).reshape(-1, self.params.big_size)
+        out = np.zeros(cts.shape[0], dtype=np.uint64)
+        _check(lib().fhe_client_decrypt(self._h, _ptr(cts), cts.shape[0], _ptr(out)))
+        return out.astype(np.int64)
+
+    def gen_server_keys(self, threads: int | None = None):
+        p = self.params
+        bsk = np.zeros(p.bsk_len, dtype=np.uint64)
+        ksk = np.zeros(p.ksk_len, dtype=np.uint64)
+        _check(lib().fhe_client_gen_server_keys(self._h, _ptr(bsk), _ptr(ksk),
+                                                threads or min(16, os.cpu_count() or 1)))
+        return bsk, ksk
+
+    def secret_keys(self):
+        p = self.params
+        g = np.zeros(p.k * p.N, dtype=np.uint64)
+        s = np.zeros(p.n, dtype=np.uint64)
+        _check(lib().fhe_client_secret_keys(self._h, _ptr(g), _ptr(s)))
+        return g, s

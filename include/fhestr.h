@@ -96,6 +96,28 @@ int fhe_lwe_lincomb_batch(fhe_engine *eng, const uint64_t *pool, uint32_t pool_c
 /* Kernel-only timing of the last fhe_ks_pbs_batch*_ call (HIP events on the engine stream):
  * ms[0] = keyswitch, ms[1] = blind rotation + sample extraction. Synchronises. */
 int fhe_last_kernel_ms(fhe_engine *eng, float ms[2]);
+/* Sum of the kernel durations of the (up to 1024) fhe_ks_pbs_batch* calls recorded since the last
+ * reset, measured with HIP events on the engine stream: total_ms[0] keyswitch, total_ms[1] blind
+ * rotation; *calls = number of calls summed.  Synchronises; reset != 0 clears the record. */
+int fhe_kernel_times(fhe_engine *eng, double total_ms[2], uint32_t *calls, int reset);
+
+/* ---- client side (CPU): keys, encryption, decryption ---------------------------------------- */
+/* ClientKey::new / encrypt / decrypt_message_and_carry / ServerKey::new of the reference
+ * (shortint/engine/client_side.rs:13-128, shortint/client_key/mod.rs:281-337,
+ * shortint/engine/server_side.rs:54-160).  Deterministic from `seed`. */
+typedef struct fhe_client_key fhe_client_key;
+size_t fhe_params_ksk_len(const fhe_params_t *p);
+size_t fhe_params_bsk_len(const fhe_params_t *p);
+int fhe_client_key_create(const fhe_params_t *params, uint64_t seed, fhe_client_key **out);
+int fhe_client_key_destroy(fhe_client_key *ck);
+/* msgs[i] in [0, msg_mod*carry_mod); cts: count x (kN+1) u64 (big-key encryption, glwe noise). */
+int fhe_client_encrypt(fhe_client_key *ck, const uint64_t *msgs, uint32_t count, uint64_t *cts);
+/* message-and-carry decode of every ciphertext. */
+int fhe_client_decrypt(fhe_client_key *ck, const uint64_t *cts, uint32_t count, uint64_t *msgs);
+/* Standard-domain BSK + KSK for fhe_engine_load_keys (sizes: fhe_params_{bsk,ksk}_len). */
+int fhe_client_gen_server_keys(fhe_client_key *ck, uint64_t *bsk_std, uint64_t *ksk, int threads);
+/* Copy out the secret keys (either pointer may be NULL): glwe_sk k*N u64, small_sk n u64. */
+int fhe_client_secret_keys(fhe_client_key *ck, uint64_t *glwe_sk, uint64_t *small_sk);
 
 #ifdef __cplusplus
 }
