@@ -161,3 +161,223 @@ int fhe_kernel_times(fhe_engine* eng, double total_ms[2], uint32_t* calls, int r
 }
 
 }  // extern "C"
+
+// ---- plans: levelised shortint circuits + FheString operations ----------------------------------
+#include "circuit.h"
+
+namespace fhe {
+int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t b_cap,
+                    const uint8_t* clear, uint32_t clear_len);
+}
+
+struct fhe_plan {
+    fhe::Circuit* c;
+    bool finalized;
+};
+
+extern "C" {
+
+int fhe_plan_create(fhe_engine* eng, fhe_plan** out) {
+    API_BEGIN
+    CHECK_PTR(out);
+    *out = nullptr;
+    CHECK_PTR(eng);
+    *out = new fhe_plan{new fhe::Circuit(eng->impl), false};
+    return 0;
+    API_END
+}
+
+int fhe_plan_destroy(fhe_plan* p) {
+    API_BEGIN
+    if (!p) return 0;
+    delete p->c;
+    delete p;
+    return 0;
+    API_END
+}
+
+#define PLAN_BUILDING(p)                                   \
+    CHECK_PTR(p);                                          \
+    if ((p)->finalized) return fail("plan already finalised")
+#define PLAN_READY(p)                                      \
+    CHECK_PTR(p);                                          \
+    if (!(p)->finalized) return fail("plan not finalised")
+
+int fhe_plan_input(fhe_plan* p, uint64_t degree, uint32_t* node) {
+    API_BEGIN
+    PLAN_BUILDING(p); CHECK_PTR(node);
+    *node = p->c->input(degree);
+    return 0;
+    API_END
+}
+
+int fhe_plan_lut(fhe_plan* p, const uint64_t* table, uint32_t* lut) {
+    API_BEGIN
+    PLAN_BUILDING(p); CHECK_PTR(table); CHECK_PTR(lut);
+    std::vector<uint64_t> t(table, table + p->c->total_modulus());
+    *lut = p->c->lut(t);
+    if (p->c->failed()) return fail(p->c->error());
+    return 0;
+    API_END
+}
+
+int fhe_plan_lin(fhe_plan* p, const uint32_t* nodes, const int32_t* coeffs, uint32_t n_terms,
+                 int64_t constant, uint32_t* node) {
+    API_BEGIN
+    PLAN_BUILDING(p); CHECK_PTR(node);
+    std::vector<fhe::Term> terms;
+    for (uint32_t i = 0; i < n_terms; i++) terms.push_back({nodes[i], coeffs[i]});
+    *node = p->c->lin(terms, constant);
+    if (p->c->failed()) return fail(p->c->error());
+    return 0;
+    API_END
+}
+
+int fhe_plan_pbs(fhe_plan* p, uint32_t src, uint32_t lut, uint32_t* node) {
+    API_BEGIN
+    PLAN_BUILDING(p); CHECK_PTR(node);
+    *node = p->c->pbs(src, lut);
+    if (p->c->failed()) return fail(p->c->error());
+    return 0;
+    API_END
+}
+
+int fhe_plan_output(fhe_plan* p, uint32_t node) {
+    API_BEGIN
+    PLAN_BUILDING(p);
+    p->c->output(node);
+    return 0;
+    API_END
+}
+
+int fhe_plan_finalize(fhe_plan* p, uint32_t world) {
+    API_BEGIN
+    PLAN_BUILDING(p);
+    if (p->c->finalize(world)) return 1;
+    p->finalized = true;
+    return 0;
+    API_END
+}
+
+int fhe_str_plan_create(fhe_engine* eng, const char* op, uint32_t a_cap, uint32_t b_cap,
+                        const uint8_t* clear, uint32_t clear_len, uint32_t world, fhe_plan** out) {
+    API_BEGIN
+    CHECK_PTR(out);
+    *out = nullptr;
+    CHECK_PTR(eng); CHECK_PTR(op);
+    fhe::Circuit* c = new fhe::Circuit(eng->impl);
+    if (fhe::build_string_op(*c, op, a_cap, b_cap, clear, clear_len) || c->finalize(world)) {
+        delete c;
+        return 1;
+    }
+    *out = new fhe_plan{c, true};
+    return 0;
+    API_END
+}
+
+int fhe_plan_info(const fhe_plan* p, uint32_t info[6]) {
+    API_BEGIN
+    PLAN_READY(p); CHECK_PTR(info);
+    info[0] = p->c->n_inputs(); info[1] = p->c->n_outputs(); info[2] = p->c->n_levels();
+    info[3] = p->c->n_pbs(); info[4] = p->c->pool_slots(); info[5] = p->c->world();
+    return 0;
+    API_END
+}
+
+static const fhe::Circuit::Level* plan_level(const fhe_plan* p, uint32_t level) {
+    if (level < p->c->n_levels()) return &p->c->level(level);
+    if (level == p->c->n_levels()) return &p->c->out_level();
+    return nullptr;
+}
+
+int fhe_plan_level_info(const fhe_plan* p, uint32_t level, uint32_t info[4]) {
+    API_BEGIN
+    PLAN_READY(p); CHECK_PTR(info);
+    const auto* lv = plan_level(p, level);
+    if (!lv) return fail("bad level");
+    info[0] = (uint32_t)lv->off.size() - 1; info[1] = lv->base; info[2] = lv->per_rank;
+    info[3] = (uint32_t)lv->src.size();
+    return 0;
+    API_END
+}
+
+int fhe_plan_export_level(const fhe_plan* p, uint32_t level, uint32_t* off, uint32_t* src,
+                          int32_t* coeff, uint64_t* cst, uint32_t* lut) {
+    API_BEGIN
+    PLAN_READY(p);
+    const auto* lv = plan_level(p, level);
+    if (!lv) return fail("bad level");
+    if (off) std::copy(lv->off.begin(), lv->off.end(), off);
+    if (src) std::copy(lv->src.begin(), lv->src.end(), src);
+    if (coeff) std::copy(lv->coeff.begin(), lv->coeff.end(), coeff);
+    if (cst) std::copy(lv->cst.begin(), lv->cst.end(), cst);
+    if (lut) std::copy(lv->lut.begin(), lv->lut.end(), lut);
+    return 0;
+    API_END
+}
+
+int fhe_plan_run(fhe_plan* p, const uint64_t* inputs, uint64_t* outputs) {
+    API_BEGIN
+    PLAN_READY(p); CHECK_PTR(outputs);
+    if (p->c->n_inputs()) CHECK_PTR(inputs);
+    return p->c->run_host(inputs, outputs);
+    API_END
+}
+
+int fhe_plan_run_level_slice_dev(fhe_plan* p, uint64_t* d_pool, uint32_t level, uint32_t lo, uint32_t hi) {
+    API_BEGIN
+    PLAN_READY(p); CHECK_PTR(d_pool);
+    return p->c->run_level_slice(d_pool, level, lo, hi);
+    API_END
+}
+
+int fhe_plan_gather_outputs_dev(fhe_plan* p, const uint64_t* d_pool, uint64_t* d_out) {
+    API_BEGIN
+    PLAN_READY(p); CHECK_PTR(d_pool); CHECK_PTR(d_out);
+    return p->c->gather_outputs(d_pool, d_out);
+    API_END
+}
+
+// one-call FheString operations (host buffers)
+static int str_op(fhe_engine* eng, const char* op, const uint64_t* a, uint32_t a_cap, const uint64_t* b,
+                  uint32_t b_cap, const uint8_t* clear, uint32_t clear_len, uint64_t* out) {
+    API_BEGIN
+    CHECK_PTR(eng); CHECK_PTR(a); CHECK_PTR(out);
+    fhe_plan* plan = nullptr;
+    if (fhe_str_plan_create(eng, op, a_cap, b_cap, clear, clear_len, 1, &plan)) return 1;
+    const size_t big = (size_t)eng->impl->p.k * eng->impl->p.N + 1;
+    std::vector<uint64_t> in((size_t)plan->c->n_inputs() * big);
+    const uint32_t bpc = plan->c->n_inputs() / (a_cap + (b ? b_cap : 0));
+    std::copy(a, a + (size_t)a_cap * bpc * big, in.begin());
+    if (b) std::copy(b, b + (size_t)b_cap * bpc * big, in.begin() + (size_t)a_cap * bpc * big);
+    int rc = plan->c->run_host(in.data(), out);
+    fhe_plan_destroy(plan);
+    return rc;
+    API_END
+}
+
+#define STR_BINARY(name)                                                                              \
+    int fhe_str_##name(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, const uint64_t* b,         \
+                       uint32_t b_cap, uint64_t* out) {                                               \
+        if (!b) return fail("null pointer: b");                                                       \
+        return str_op(eng, #name, a, a_cap, b, b_cap, nullptr, 0, out);                               \
+    }                                                                                                 \
+    int fhe_str_##name##_clear(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, const uint8_t* pat, \
+                               uint32_t pat_len, uint64_t* out) {                                     \
+        return str_op(eng, #name "_clear", a, a_cap, nullptr, 0, pat, pat_len, out);                  \
+    }
+STR_BINARY(eq)
+STR_BINARY(ne)
+STR_BINARY(starts_with)
+STR_BINARY(ends_with)
+STR_BINARY(contains)
+STR_BINARY(find)
+
+int fhe_str_to_upper(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, uint64_t* out) {
+    return str_op(eng, "to_upper", a, a_cap, nullptr, 0, nullptr, 0, out);
+}
+int fhe_str_to_lower(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, uint64_t* out) {
+    return str_op(eng, "to_lower", a, a_cap, nullptr, 0, nullptr, 0, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,256 @@
+// circuit.cpp -- builder, leveliser and GPU executor of shortint circuits (see circuit.h).
+#include "circuit.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace fhe {
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+    } while (0)
+
+uint32_t Circuit::input(uint64_t degree) {
+    Node n;
+    n.kind = Node::INPUT;
+    n.level = 0;
+    n.degree = degree;
+    n.slot = n_inputs_++;
+    nodes_.push_back(n);
+    return (uint32_t)nodes_.size() - 1;
+}
+
+void Circuit::flatten(uint32_t id, int64_t mult, std::map<uint32_t, int64_t>& acc, int64_t& cst) const {
+    const Node& n = nodes_[id];
+    if (n.kind == Node::LIN) {
+        for (const Term& t : n.terms) acc[t.node] += mult * t.coeff;   // already flat
+        cst += mult * n.cst;
+    } else {
+        acc[id] += mult;
+    }
+}
+
+uint32_t Circuit::lin(const std::vector<Term>& terms, int64_t cst, int64_t degree_override) {
+    std::map<uint32_t, int64_t> acc;
+    int64_t c = cst;
+    for (const Term& t : terms) {
+        if (t.node >= nodes_.size()) { error_ = "lin: bad node id"; return 0; }
+        flatten(t.node, t.coeff, acc, c);
+    }
+    Node n;
+    n.kind = Node::LIN;
+    n.cst = c;
+    uint32_t lvl = 0;
+    int64_t maxv = c > 0 ? c : 0;
+    for (auto& kv : acc) {
+        if (kv.second == 0) continue;
+        if (kv.second > INT32_MAX || kv.second < INT32_MIN) { error_ = "lin: coefficient overflow"; return 0; }
+        n.terms.push_back({kv.first, (int32_t)kv.second});
+        lvl = std::max(lvl, nodes_[kv.first].level);
+        if (kv.second > 0) maxv += kv.second * (int64_t)nodes_[kv.first].degree;
+    }
+    n.level = lvl;
+    n.degree = degree_override >= 0 ? (uint64_t)degree_override : (uint64_t)maxv;
+    nodes_.push_back(n);
+    return (uint32_t)nodes_.size() - 1;
+}
+
+uint32_t Circuit::lut(const std::vector<uint64_t>& table) {
+    auto it = lut_cache_.find(table);
+    if (it != lut_cache_.end()) return it->second;
+    if (table.size() != total_modulus()) { error_ = "lut: table size must be msg_mod*carry_mod"; return 0; }
+    std::vector<uint64_t> acc;
+    eng_->fill_accumulator(table.data(), acc);
+    uint32_t id = 0;
+    if (eng_->lut_upload(acc.data(), &id)) { error_ = "lut upload failed: " + g_last_error; return 0; }
+    lut_cache_[table] = id;
+    return id;
+}
+
+uint32_t Circuit::pbs(uint32_t id, uint32_t lut_id) {
+    if (id >= nodes_.size()) { error_ = "pbs: bad node id"; return 0; }
+    const std::vector<uint64_t>* table = nullptr;
+    for (auto& kv : lut_cache_)
+        if (kv.second == lut_id) table = &kv.first;
+    if (!table) { error_ = "pbs: LUT was not created through this circuit"; return 0; }
+    uint32_t src = id;
+    if (nodes_[id].kind != Node::LIN) src = lin({{id, 1}});
+    const Node& s = nodes_[src];
+    if (s.degree >= total_modulus()) {
+        error_ = "pbs: input degree " + std::to_string(s.degree) + " overflows the message+carry space";
+        return 0;
+    }
+    if (s.terms.empty()) {
+        // trivial ciphertext: clear table lookup (shortint/server_key/mod.rs:763-781)
+        const int64_t v = s.cst;
+        if (v < 0 || v >= (int64_t)total_modulus()) { error_ = "pbs: trivial value out of range"; return 0; }
+        return trivial((int64_t)(*table)[(size_t)v]);
+    }
+    Node n;
+    n.kind = Node::PBS;
+    n.src = src;
+    n.lut = lut_id;
+    n.level = s.level + 1;
+    n.degree = *std::max_element(table->begin(), table->end());   // mod.rs:855
+    nodes_.push_back(n);
+    n_pbs_++;
+    return (uint32_t)nodes_.size() - 1;
+}
+
+void Circuit::build_csr(Level& lv, const std::vector<uint32_t>& lin_nodes) {
+    const uint64_t delta = (1ull << 63) / total_modulus();
+    lv.off.assign(1, 0);
+    lv.src.clear(); lv.coeff.clear(); lv.cst.clear();
+    for (uint32_t id : lin_nodes) {
+        const Node& s = nodes_[id];
+        if (s.kind == Node::LIN) {
+            for (const Term& t : s.terms) {
+                lv.src.push_back(nodes_[t.node].slot);
+                lv.coeff.push_back(t.coeff);
+            }
+            lv.cst.push_back((uint64_t)s.cst * delta);
+        } else {
+            lv.src.push_back(s.slot);
+            lv.coeff.push_back(1);
+            lv.cst.push_back(0);
+        }
+        lv.off.push_back((uint32_t)lv.src.size());
+    }
+}
+
+int Circuit::finalize(uint32_t world) {
+    if (failed()) return fail("circuit build error: " + error_);
+    if (world == 0) return fail("world must be >= 1");
+    world_ = world;
+    uint32_t max_level = 0;
+    for (const Node& n : nodes_)
+        if (n.kind == Node::PBS) max_level = std::max(max_level, n.level);
+    levels_.assign(max_level, Level());
+    for (uint32_t id = 0; id < nodes_.size(); id++)
+        if (nodes_[id].kind == Node::PBS) levels_[nodes_[id].level - 1].jobs.push_back(id);
+    uint32_t base = n_inputs_;
+    for (auto& lv : levels_) {
+        const uint32_t J = (uint32_t)lv.jobs.size();
+        lv.per_rank = (J + world - 1) / world;
+        lv.base = base;
+        for (uint32_t j = 0; j < J; j++) {
+            nodes_[lv.jobs[j]].slot = base + j;
+            nodes_[lv.jobs[j]].job = j;
+        }
+        base += lv.per_rank * world;
+    }
+    pool_slots_ = base;
+    for (auto& lv : levels_) {
+        std::vector<uint32_t> srcs;
+        lv.lut.clear();
+        for (uint32_t id : lv.jobs) {
+            srcs.push_back(nodes_[id].src);
+            lv.lut.push_back(nodes_[id].lut);
+        }
+        build_csr(lv, srcs);
+    }
+    build_csr(out_, outputs_);
+    return upload_meta();
+}
+
+static size_t align8(size_t x) { return (x + 7) / 8 * 8; }
+
+int Circuit::upload_meta() {
+    if (eng_->use()) return 1;
+    size_t total = 0;
+    auto place = [&](Level& lv) {
+        lv.meta_off = total;   total += align8(lv.off.size() * 4);
+        lv.meta_src = total;   total += align8((lv.src.size() + 1) * 4);
+        lv.meta_coeff = total; total += align8((lv.coeff.size() + 1) * 4);
+        lv.meta_cst = total;   total += align8((lv.cst.size() + 1) * 8);
+        lv.meta_lut = total;   total += align8((lv.lut.size() + 1) * 4);
+    };
+    for (auto& lv : levels_) place(lv);
+    place(out_);
+    std::vector<unsigned char> host(total, 0);
+    auto fill = [&](const Level& lv) {
+        std::memcpy(host.data() + lv.meta_off, lv.off.data(), lv.off.size() * 4);
+        std::memcpy(host.data() + lv.meta_src, lv.src.data(), lv.src.size() * 4);
+        std::memcpy(host.data() + lv.meta_coeff, lv.coeff.data(), lv.coeff.size() * 4);
+        std::memcpy(host.data() + lv.meta_cst, lv.cst.data(), lv.cst.size() * 8);
+        std::memcpy(host.data() + lv.meta_lut, lv.lut.data(), lv.lut.size() * 4);
+    };
+    for (auto& lv : levels_) fill(lv);
+    fill(out_);
+    if (d_meta_) { HIP_TRY(hipFree(d_meta_)); d_meta_ = nullptr; }
+    HIP_TRY(hipMalloc(&d_meta_, total ? total : 8));
+    HIP_TRY(hipMemcpyAsync(d_meta_, host.data(), total, hipMemcpyHostToDevice, eng_->stream));
+    HIP_TRY(hipStreamSynchronize(eng_->stream));
+    size_t max_jobs = 1;
+    for (auto& lv : levels_) max_jobs = std::max(max_jobs, (size_t)lv.per_rank);
+    const size_t big = (size_t)eng_->p.k * eng_->p.N + 1;
+    if (stage_cap_ < max_jobs * big * 8) {
+        if (d_stage_) HIP_TRY(hipFree(d_stage_));
+        d_stage_ = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_stage_, max_jobs * big * 8));
+        stage_cap_ = max_jobs * big * 8;
+    }
+    return 0;
+}
+
+int Circuit::run_level_slice(uint64_t* d_pool, uint32_t l, uint32_t lo, uint32_t hi) {
+    if (l >= levels_.size()) return fail("bad level");
+    const Level& lv = levels_[l];
+    hi = std::min<uint32_t>(hi, (uint32_t)lv.jobs.size());
+    if (lo >= hi) return 0;
+    if (hi - lo > lv.per_rank && world_ > 1) return fail("slice larger than the per-rank region");
+    if (eng_->use()) return 1;
+    const size_t big = (size_t)eng_->p.k * eng_->p.N + 1;
+    if ((size_t)(hi - lo) * big * 8 > stage_cap_) {
+        if (d_stage_) HIP_TRY(hipFree(d_stage_));
+        d_stage_ = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_stage_, (size_t)(hi - lo) * big * 8));
+        stage_cap_ = (size_t)(hi - lo) * big * 8;
+    }
+    const unsigned char* m = reinterpret_cast<const unsigned char*>(d_meta_);
+    const uint32_t* d_off = reinterpret_cast<const uint32_t*>(m + lv.meta_off) + lo;
+    const uint32_t* d_src = reinterpret_cast<const uint32_t*>(m + lv.meta_src);
+    const int32_t* d_coeff = reinterpret_cast<const int32_t*>(m + lv.meta_coeff);
+    const uint64_t* d_cst = reinterpret_cast<const uint64_t*>(m + lv.meta_cst) + lo;
+    const uint32_t* d_lut = reinterpret_cast<const uint32_t*>(m + lv.meta_lut) + lo;
+    if (eng_->lincomb_dev(d_pool, d_off, d_src, d_coeff, d_cst, d_stage_, hi - lo)) return 1;
+    return eng_->ks_pbs_dev(d_stage_, d_lut, d_pool + (size_t)(lv.base + lo) * big, hi - lo);
+}
+
+int Circuit::gather_outputs(const uint64_t* d_pool, uint64_t* d_out) {
+    if (eng_->use()) return 1;
+    const unsigned char* m = reinterpret_cast<const unsigned char*>(d_meta_);
+    return eng_->lincomb_dev(d_pool, reinterpret_cast<const uint32_t*>(m + out_.meta_off),
+                             reinterpret_cast<const uint32_t*>(m + out_.meta_src),
+                             reinterpret_cast<const int32_t*>(m + out_.meta_coeff),
+                             reinterpret_cast<const uint64_t*>(m + out_.meta_cst), d_out, n_outputs());
+}
+
+int Circuit::run_host(const uint64_t* inputs, uint64_t* outputs) {
+    if (eng_->use()) return 1;
+    if (world_ != 1) return fail("run_host needs a plan finalised for world = 1");
+    const size_t big = (size_t)eng_->p.k * eng_->p.N + 1;
+    if (!d_own_pool_) HIP_TRY(hipMalloc((void**)&d_own_pool_, (size_t)std::max<uint32_t>(pool_slots_, 1) * big * 8));
+    if (!d_own_out_) HIP_TRY(hipMalloc((void**)&d_own_out_, (size_t)std::max<uint32_t>(n_outputs(), 1) * big * 8));
+    if (n_inputs_)
+        HIP_TRY(hipMemcpyAsync(d_own_pool_, inputs, (size_t)n_inputs_ * big * 8, hipMemcpyHostToDevice, eng_->stream));
+    for (uint32_t l = 0; l < levels_.size(); l++)
+        if (run_level_slice(d_own_pool_, l, 0, (uint32_t)levels_[l].jobs.size())) return 1;
+    if (gather_outputs(d_own_pool_, d_own_out_)) return 1;
+    HIP_TRY(hipMemcpyAsync(outputs, d_own_out_, (size_t)n_outputs() * big * 8, hipMemcpyDeviceToHost, eng_->stream));
+    HIP_TRY(hipStreamSynchronize(eng_->stream));
+    return 0;
+}
+
+Circuit::~Circuit() {
+    (void)hipSetDevice(eng_->device);
+    if (d_meta_) (void)hipFree(d_meta_);
+    if (d_stage_) (void)hipFree(d_stage_);
+    if (d_own_pool_) (void)hipFree(d_own_pool_);
+    if (d_own_out_) (void)hipFree(d_own_out_);
+}
+
+}  // namespace fhe

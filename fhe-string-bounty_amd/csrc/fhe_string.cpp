@@ -1,0 +1,424 @@
+// fhe_string.cpp -- FheString operations as batched shortint circuits.
+//
+// The reference snapshot has no FheString type; its building blocks are the integer
+// layer's block-wise comparison loops, restated here on whole strings:
+//   unchecked_eq / unchecked_ne            integer/server_key/radix_parallel/comparison.rs:10-83
+//   unchecked_scalar_eq / _ne (+ packing)  .../scalar_comparison.rs:104-138,366-558
+//   are_all_comparisons_block_true         .../scalar_comparison.rs:147-191
+//   is_at_least_one_comparisons_block_true .../scalar_comparison.rs:200-233
+//   compare_blocks_with_zero               .../scalar_comparison.rs:254-296
+// and the char-wise patterns of the docs tutorial / regex engine
+// (tfhe/docs/tutorials/ascii_fhe_string.md:84-131, tfhe/examples/regex_engine/execution.rs:63-86).
+//
+// An FheString is `cap` characters, zero padded; one 8-bit character = 8/log2(msg_mod) shortint
+// blocks, little endian (integer/block_decomposition.rs:119-144).  Semantics of every operation =
+// the corresponding clear-text function on the unpadded ASCII string.
+#include <algorithm>
+#include <cstring>
+
+#include "circuit.h"
+
+namespace fhe {
+
+struct Str {
+    uint32_t cap = 0;
+    std::vector<std::vector<uint32_t>> ch;   // [char][block] node ids
+};
+
+class StrOps {
+public:
+    explicit StrOps(Circuit& c) : c(c) {
+        M = c.msg_modulus();
+        T = c.total_modulus();
+        bits_per_block = 0;
+        while ((1u << bits_per_block) < M) bits_per_block++;
+        bpc = 8 / bits_per_block;
+        ok = (1u << bits_per_block) == M && 8 % bits_per_block == 0 && T / M >= M;
+    }
+    Circuit& c;
+    uint32_t M, T, bits_per_block, bpc;
+    bool ok;
+
+    Str input_string(uint32_t cap) {
+        Str s;
+        s.cap = cap;
+        s.ch.resize(cap);
+        for (auto& blocks : s.ch)
+            for (uint32_t b = 0; b < bpc; b++) blocks.push_back(c.input(M - 1));
+        return s;
+    }
+    // clear byte -> block digits (integer/block_decomposition.rs:119-144)
+    uint32_t clear_block(uint8_t v, uint32_t b) const { return (v >> (b * bits_per_block)) & (M - 1); }
+
+    // ---- reductions of 0/1 blocks ----
+    // are_all_comparisons_block_true (scalar_comparison.rs:147-191)
+    uint32_t all_true(std::vector<uint32_t> bits) {
+        if (bits.empty()) return c.trivial(1);
+        const uint32_t max_value = T - 1;
+        while (bits.size() > 1) {
+            std::vector<uint32_t> next;
+            for (size_t i = 0; i < bits.size(); i += max_value) {
+                const size_t len = std::min<size_t>(max_value, bits.size() - i);
+                std::vector<Term> terms;
+                for (size_t j = 0; j < len; j++) terms.push_back({bits[i + j], 1});
+                const uint32_t l = c.lut_fn([len](uint64_t x) { return (uint64_t)(x == len); });
+                next.push_back(c.pbs(c.lin(terms), l));
+            }
+            bits.swap(next);
+        }
+        return bits[0];
+    }
+    // is_at_least_one_comparisons_block_true (scalar_comparison.rs:200-233)
+    uint32_t any_true(std::vector<uint32_t> bits) {
+        if (bits.empty()) return c.trivial(0);
+        const uint32_t max_value = T - 1;
+        const uint32_t nz = c.lut_fn([](uint64_t x) { return (uint64_t)(x != 0); });
+        while (bits.size() > 1) {
+            std::vector<uint32_t> next;
+            for (size_t i = 0; i < bits.size(); i += max_value) {
+                const size_t len = std::min<size_t>(max_value, bits.size() - i);
+                std::vector<Term> terms;
+                for (size_t j = 0; j < len; j++) terms.push_back({bits[i + j], 1});
+                next.push_back(c.pbs(c.lin(terms), nz));
+            }
+            bits.swap(next);
+        }
+        return bits[0];
+    }
+
+    // ---- block-level comparisons ----
+    // bivariate LUT on lhs*M + rhs (bivariate_pbs.rs:71-96,167-182)
+    uint32_t block_eq(uint32_t a, uint32_t b, bool want_equal) {
+        const uint32_t m = M;
+        const uint32_t l = c.lut_fn([m, want_equal](uint64_t x) {
+            const uint64_t lhs = (x / m) % m, rhs = (x % m) % m;
+            return (uint64_t)((lhs == rhs) == want_equal);
+        });
+        return c.pbs(c.lin({{a, (int32_t)M}, {b, 1}}), l);
+    }
+    // pack_block_chunk + scalar LUT (scalar_comparison.rs:104-138,312-336,431-452): two blocks of a
+    // char packed as hi*M + lo, compared with the clear value packed the same way.
+    uint32_t packed_scalar_cmp(uint32_t lo, uint32_t hi, uint32_t clear, bool want_equal) {
+        const uint32_t l = c.lut_fn([clear, want_equal](uint64_t x) { return (uint64_t)((x == clear) == want_equal); });
+        return c.pbs(c.lin({{hi, (int32_t)M}, {lo, 1}}), l);
+    }
+    // 0/1 blocks saying char == clear byte (want_equal) / != per packed pair
+    void char_scalar_bits(const std::vector<uint32_t>& blocks, uint8_t v, bool want_equal, std::vector<uint32_t>& out) {
+        for (uint32_t b = 0; b + 1 < bpc; b += 2) {
+            const uint32_t clear = clear_block(v, b + 1) * M + clear_block(v, b);
+            out.push_back(packed_scalar_cmp(blocks[b], blocks[b + 1], clear, want_equal));
+        }
+    }
+    // one 0/1 block: char == clear byte
+    uint32_t char_scalar_eq(const std::vector<uint32_t>& blocks, uint8_t v) {
+        std::vector<uint32_t> bits;
+        char_scalar_bits(blocks, v, true, bits);
+        return all_true(bits);
+    }
+    // compare_blocks_with_zero (scalar_comparison.rs:254-296): one 0/1 block, char == 0
+    uint32_t char_is_zero(const std::vector<uint32_t>& blocks) {
+        const uint32_t per = (T - 1) / (M - 1);
+        const uint32_t tt = T;
+        const uint32_t z = c.lut_fn([tt](uint64_t x) { return (uint64_t)((x % tt) == 0); });
+        std::vector<uint32_t> bits;
+        for (size_t i = 0; i < blocks.size(); i += per) {
+            std::vector<Term> terms;
+            for (size_t j = i; j < std::min(blocks.size(), i + per); j++) terms.push_back({blocks[j], 1});
+            bits.push_back(c.pbs(c.lin(terms), z));
+        }
+        return all_true(bits);
+    }
+    const std::vector<uint32_t>* ch_or_null(const Str& s, uint32_t i) const { return i < s.cap ? &s.ch[i] : nullptr; }
+
+    // ---- whole-string equality ----
+    uint32_t eq(const Str& a, const Str& b, bool want_equal) {
+        const uint32_t n = std::max(a.cap, b.cap);
+        std::vector<uint32_t> bits;
+        for (uint32_t i = 0; i < n; i++) {
+            const auto* x = ch_or_null(a, i);
+            const auto* y = ch_or_null(b, i);
+            if (x && y) {
+                for (uint32_t k = 0; k < bpc; k++) bits.push_back(block_eq((*x)[k], (*y)[k], want_equal));
+            } else {
+                // the shorter string is implicitly zero padded: compare the other one's char with 0
+                std::vector<uint32_t> one;
+                char_scalar_bits(x ? *x : *y, 0, want_equal, one);
+                bits.insert(bits.end(), one.begin(), one.end());
+            }
+        }
+        return want_equal ? all_true(bits) : any_true(bits);
+    }
+    uint32_t eq_clear(const Str& a, const uint8_t* clear, uint32_t len, bool want_equal) {
+        for (uint32_t i = a.cap; i < len; i++)
+            if (clear[i] != 0) return c.trivial(want_equal ? 0 : 1);   // longer than the capacity
+        std::vector<uint32_t> bits;
+        for (uint32_t i = 0; i < a.cap; i++) char_scalar_bits(a.ch[i], i < len ? clear[i] : 0, want_equal, bits);
+        return want_equal ? all_true(bits) : any_true(bits);
+    }
+
+    // ---- pattern matching with an encrypted, zero padded pattern ----
+    // z[i] = [pat[i] == 0]
+    std::vector<uint32_t> pattern_zero_bits(const Str& pat) {
+        std::vector<uint32_t> z;
+        for (uint32_t i = 0; i < pat.cap; i++) z.push_back(char_is_zero(pat.ch[i]));
+        return z;
+    }
+    // sum of the bpc block-equality bits of (s[ci], pat[pi]); s beyond its capacity is null.
+    // returns a LIN node with value in [0, bpc] (bpc == chars equal)
+    uint32_t char_eq_sum(const Str& s, uint32_t ci, const Str& pat, uint32_t pi,
+                         std::map<std::pair<uint32_t, uint32_t>, uint32_t>& memo) {
+        auto key = std::make_pair(ci, pi);
+        auto it = memo.find(key);
+        if (it != memo.end()) return it->second;
+        std::vector<Term> terms;
+        for (uint32_t k = 0; k < bpc; k++) terms.push_back({block_eq(s.ch[ci][k], pat.ch[pi][k], true), 1});
+        return memo[key] = c.lin(terms);
+    }
+    // t = [pat[pi] == 0] OR [s[ci] == pat[pi]]  (prefix-style match: pattern padding matches anything)
+    // q = [s[ci] == pat[pi]]                    (exact match incl. padding)
+    uint32_t char_match(const Str& s, uint32_t ci, const Str& pat, uint32_t pi, const std::vector<uint32_t>& z,
+                        bool padding_wildcard, std::map<std::pair<uint32_t, uint32_t>, uint32_t>& sums,
+                        std::map<std::pair<uint32_t, uint32_t>, uint32_t>& memo) {
+        if (ci >= s.cap) return z[pi];   // null char: equal iff pat[pi] == 0 (both readings)
+        auto key = std::make_pair(ci, pi);
+        auto it = memo.find(key);
+        if (it != memo.end()) return it->second;
+        const uint32_t sum = char_eq_sum(s, ci, pat, pi, sums);
+        const uint32_t n = bpc;
+        uint32_t r;
+        if (padding_wildcard) {
+            // value = eq_sum + (bpc+1)*z  ->  match iff value >= bpc
+            const uint32_t l = c.lut_fn([n](uint64_t x) { return (uint64_t)(x >= n); });
+            r = c.pbs(c.lin({{sum, 1}, {z[pi], (int32_t)(bpc + 1)}}), l);
+        } else {
+            const uint32_t l = c.lut_fn([n](uint64_t x) { return (uint64_t)(x == n); });
+            r = c.pbs(sum, l);
+        }
+        return memo[key] = r;
+    }
+    // match[o] for o in [0, n_off): AND_i char_match(s[o+i], pat[i])
+    // need_end: additionally require the string to end right after the window (s[o+pat.cap] null)
+    std::vector<uint32_t> window_matches(const Str& s, const Str& pat, uint32_t n_off, bool padding_wildcard,
+                                         bool need_end = false) {
+        std::vector<uint32_t> z = pattern_zero_bits(pat);
+        std::map<std::pair<uint32_t, uint32_t>, uint32_t> sums, memo;
+        std::map<uint32_t, uint32_t> s_zero;
+        std::vector<uint32_t> match;
+        for (uint32_t o = 0; o < n_off; o++) {
+            std::vector<uint32_t> bits;
+            for (uint32_t i = 0; i < pat.cap; i++)
+                bits.push_back(char_match(s, o + i, pat, i, z, padding_wildcard, sums, memo));
+            if (need_end && o + pat.cap < s.cap) {
+                auto it = s_zero.find(o + pat.cap);
+                if (it == s_zero.end()) it = s_zero.emplace(o + pat.cap, char_is_zero(s.ch[o + pat.cap])).first;
+                bits.push_back(it->second);
+            }
+            match.push_back(all_true(bits));
+        }
+        return match;
+    }
+    // clear pattern: match[o] = AND_{i<len} [s[o+i] == pat[i]], o + len <= cap
+    std::vector<uint32_t> window_matches_clear(const Str& s, const uint8_t* pat, uint32_t len, uint32_t n_off) {
+        std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> memo;   // (char, byte) -> bits
+        std::vector<uint32_t> match;
+        for (uint32_t o = 0; o < n_off; o++) {
+            std::vector<uint32_t> bits;
+            for (uint32_t i = 0; i < len; i++) {
+                auto key = std::make_pair(o + i, (uint32_t)pat[i]);
+                auto it = memo.find(key);
+                if (it == memo.end()) {
+                    std::vector<uint32_t> b;
+                    char_scalar_bits(s.ch[o + i], pat[i], true, b);
+                    it = memo.emplace(key, b).first;
+                }
+                bits.insert(bits.end(), it->second.begin(), it->second.end());
+            }
+            match.push_back(all_true(bits));
+        }
+        return match;
+    }
+
+    uint32_t starts_with(const Str& s, const Str& pat) { return window_matches(s, pat, 1, true)[0]; }
+    uint32_t starts_with_clear(const Str& s, const uint8_t* pat, uint32_t len) {
+        if (len > s.cap) return c.trivial(0);
+        if (len == 0) return c.trivial(1);
+        return window_matches_clear(s, pat, len, 1)[0];
+    }
+    uint32_t contains(const Str& s, const Str& pat) { return any_true(window_matches(s, pat, s.cap, true)); }
+    uint32_t contains_clear(const Str& s, const uint8_t* pat, uint32_t len) {
+        if (len > s.cap) return c.trivial(0);
+        if (len == 0) return c.trivial(1);
+        return any_true(window_matches_clear(s, pat, len, s.cap - len + 1));
+    }
+    // ends_with: some suffix of s (incl. the empty one at offset cap) equals the whole padded pattern
+    uint32_t ends_with(const Str& s, const Str& pat) { return any_true(window_matches(s, pat, s.cap + 1, false, true)); }
+    uint32_t ends_with_clear(const Str& s, const uint8_t* pat, uint32_t len) {
+        if (len > s.cap) return c.trivial(0);
+        if (len == 0) return c.trivial(1);
+        // s[o..o+len) == pat and (o+len == cap or s[o+len] == 0)
+        std::vector<uint32_t> m = window_matches_clear(s, pat, len, s.cap - len + 1);
+        std::vector<uint32_t> cand;
+        for (uint32_t o = 0; o + len <= s.cap; o++) {
+            if (o + len == s.cap) { cand.push_back(m[o]); continue; }
+            const uint32_t zend = char_is_zero(s.ch[o + len]);
+            const uint32_t l = c.lut_fn([](uint64_t x) { return (uint64_t)(x == 2); });
+            cand.push_back(c.pbs(c.lin({{m[o], 1}, {zend, 1}}), l));
+        }
+        return any_true(cand);
+    }
+
+    // ---- find: (found, index digits) of the first match ----
+    // prefix_any[o] = OR_{o' <= o} bits[o'] through a blocked scan (fan-in T-1 per PBS)
+    std::vector<uint32_t> prefix_or(const std::vector<uint32_t>& bits) {
+        const uint32_t F = T - 1;
+        const uint32_t nz = c.lut_fn([](uint64_t x) { return (uint64_t)(x != 0); });
+        const size_t n = bits.size();
+        if (n <= 1) return bits;
+        std::vector<uint32_t> within(n), block_tot;
+        for (size_t b = 0; b < n; b += F) {
+            std::vector<Term> run;
+            for (size_t j = b; j < std::min(n, b + F); j++) {
+                run.push_back({bits[j], 1});
+                within[j] = run.size() == 1 ? bits[j] : c.pbs(c.lin(run), nz);
+            }
+            block_tot.push_back(within[std::min(n, b + F) - 1]);
+        }
+        if (block_tot.size() == 1) return within;
+        std::vector<uint32_t> block_pre = prefix_or(block_tot);   // inclusive prefix over blocks
+        std::vector<uint32_t> out(n);
+        for (size_t j = 0; j < n; j++) {
+            const size_t b = j / F;
+            out[j] = b == 0 ? within[j] : c.pbs(c.lin({{within[j], 1}, {block_pre[b - 1], 1}}), nz);
+        }
+        return out;
+    }
+    // outputs: found bit, then n_digits base-M digits (little endian) of the first matching offset
+    void find_from_matches(const std::vector<uint32_t>& match, uint32_t n_digits, std::vector<uint32_t>& out) {
+        std::vector<uint32_t> pre = prefix_or(match);
+        const uint32_t found = pre.back();
+        // first[o] = match[o] AND NOT pre[o-1]  ==  (match[o] + 2*pre[o-1]) == 1
+        const uint32_t first_lut = c.lut_fn([](uint64_t x) { return (uint64_t)(x == 1); });
+        std::vector<uint32_t> first(match.size());
+        for (size_t o = 0; o < match.size(); o++)
+            first[o] = o == 0 ? match[0] : c.pbs(c.lin({{match[o], 1}, {pre[o - 1], 2}}), first_lut);
+        out.push_back(found);
+        const uint32_t F = T - 1;
+        for (uint32_t d = 0; d < n_digits; d++) {
+            // digit d of the index = sum_o first[o] * digit_d(o): at most one term is non-zero
+            std::vector<uint32_t> parts;
+            for (size_t b = 0; b < first.size(); b += F) {
+                std::vector<Term> terms;
+                for (size_t o = b; o < std::min(first.size(), b + F); o++) {
+                    const uint32_t dig = (uint32_t)((o >> (d * bits_per_block)) & (M - 1));
+                    if (dig) terms.push_back({first[o], (int32_t)dig});
+                }
+                // degree bookkeeping: at most one `first` is 1, so the true bound is M-1
+                if (!terms.empty()) parts.push_back(c.lin(terms, 0, (int64_t)M - 1));
+            }
+            const uint32_t mm = M;
+            const uint32_t idm = c.lut_fn([mm](uint64_t x) { return x % mm; });
+            std::vector<uint32_t> cleaned;
+            for (uint32_t p : parts) cleaned.push_back(c.pbs(p, idm));   // also resets the noise
+            // again at most one part is non-zero: sums stay <= M-1
+            while (cleaned.size() > 1) {
+                std::vector<uint32_t> next;
+                for (size_t i = 0; i < cleaned.size(); i += F) {
+                    std::vector<Term> terms;
+                    for (size_t j = i; j < std::min(cleaned.size(), i + F); j++) terms.push_back({cleaned[j], 1});
+                    next.push_back(c.pbs(c.lin(terms, 0, (int64_t)M - 1), idm));
+                }
+                cleaned.swap(next);
+            }
+            out.push_back(cleaned.empty() ? c.trivial(0) : cleaned[0]);
+        }
+    }
+
+    // ---- case conversion (docs/tutorials/ascii_fhe_string.md:88-131 semantics) ----
+    // to_lower: c in ['A','Z'] -> c + 32 ; to_upper: c in ['a','z'] -> c - 32.  32 = 2 * 16 only
+    // touches bit 5, i.e. block (5 / bits_per_block); letters never carry out of that block.
+    void change_case(const Str& s, bool to_lower, std::vector<uint32_t>& out) {
+        const uint32_t lo_first = to_lower ? 'A' : 'a', lo_last = to_lower ? 'Z' : 'z';
+        const uint32_t hiA = lo_first >> 4, hiB = lo_last >> 4;          // 4 / 5  or  6 / 7
+        const uint32_t loA = lo_first & 15, loB = lo_last & 15;         // 1 and 10
+        const uint32_t blk = 5 / bits_per_block, bit_in_blk = 5 % bits_per_block;
+        const uint32_t addv = 1u << bit_in_blk;
+        // level 1: classify high nibble (0 / 1 = first row / 2 = second row) and low nibble
+        // (bit0 = lo >= loA, bit1 = lo <= loB); level 2: combine into addv * is_letter
+        const uint32_t hi_lut = c.lut_fn([hiA, hiB](uint64_t x) { return (uint64_t)(x == hiA ? 1 : (x == hiB ? 2 : 0)); });
+        const uint32_t lo_lut = c.lut_fn([loA, loB](uint64_t x) { return (uint64_t)((x >= loA ? 1 : 0) | (x <= loB ? 2 : 0)); });
+        const uint32_t comb = c.lut_fn([addv](uint64_t x) {
+            const uint64_t a = x / 4, b = x % 4;
+            const bool is = (a == 1 && (b & 1)) || (a == 2 && (b & 2));
+            return (uint64_t)(is ? addv : 0);
+        });
+        const uint32_t half = bpc / 2;   // blocks per nibble (2 for 2-bit blocks)
+        for (uint32_t i = 0; i < s.cap; i++) {
+            const auto& b = s.ch[i];
+            std::vector<Term> lo_terms, hi_terms;
+            for (uint32_t k = 0; k < half; k++) {
+                lo_terms.push_back({b[k], (int32_t)(1u << (k * bits_per_block))});
+                hi_terms.push_back({b[half + k], (int32_t)(1u << (k * bits_per_block))});
+            }
+            const uint32_t hc = c.pbs(c.lin(hi_terms), hi_lut);
+            const uint32_t lc = c.pbs(c.lin(lo_terms), lo_lut);
+            const uint32_t delta = c.pbs(c.lin({{hc, 4}, {lc, 1}}), comb);
+            for (uint32_t k = 0; k < bpc; k++) {
+                if (k == blk) out.push_back(c.lin({{b[k], 1}, {delta, to_lower ? 1 : -1}}));
+                else out.push_back(b[k]);
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// op dispatch used by the C ABI: builds the circuit for `op` and declares its outputs
+int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t b_cap,
+                    const uint8_t* clear, uint32_t clear_len) {
+    StrOps s(c);
+    if (!s.ok) return fail("string ops need msg_mod = 2^b with b | 8 and carry_mod >= msg_mod");
+    if (a_cap == 0) return fail("string capacity must be > 0");
+    const bool is_clear = op.size() > 6 && op.compare(op.size() - 6, 6, "_clear") == 0;
+    const std::string base = is_clear ? op.substr(0, op.size() - 6) : op;
+    if (is_clear && !clear && clear_len) return fail("null clear pattern");
+    Str a = s.input_string(a_cap);
+    Str b;
+    const bool unary = base == "to_upper" || base == "to_lower";
+    if (!is_clear && !unary) {
+        if (b_cap == 0) return fail("pattern capacity must be > 0");
+        b = s.input_string(b_cap);
+    }
+    uint32_t n_digits = 0;
+    while ((1ull << (n_digits * s.bits_per_block)) < (uint64_t)a_cap + 1) n_digits++;
+    if (base == "eq" || base == "ne") {
+        const bool want = base == "eq";
+        c.output(is_clear ? s.eq_clear(a, clear, clear_len, want) : s.eq(a, b, want));
+    } else if (base == "starts_with") {
+        c.output(is_clear ? s.starts_with_clear(a, clear, clear_len) : s.starts_with(a, b));
+    } else if (base == "ends_with") {
+        c.output(is_clear ? s.ends_with_clear(a, clear, clear_len) : s.ends_with(a, b));
+    } else if (base == "contains") {
+        c.output(is_clear ? s.contains_clear(a, clear, clear_len) : s.contains(a, b));
+    } else if (base == "find") {
+        std::vector<uint32_t> match;
+        if (is_clear) {
+            if (clear_len > a_cap) match.assign(1, c.trivial(0));
+            else if (clear_len == 0) match.assign(1, c.trivial(1));
+            else match = s.window_matches_clear(a, clear, clear_len, a_cap - clear_len + 1);
+        } else {
+            match = s.window_matches(a, b, a_cap, true);
+        }
+        std::vector<uint32_t> outs;
+        s.find_from_matches(match, n_digits, outs);
+        for (uint32_t o : outs) c.output(o);
+    } else if (unary) {
+        std::vector<uint32_t> outs;
+        s.change_case(a, base == "to_lower", outs);
+        for (uint32_t o : outs) c.output(o);
+    } else {
+        return fail("unknown string op: " + op);
+    }
+    if (c.failed()) return fail("circuit build error: " + c.error());
+    return 0;
+}
+
+}  // namespace fhe

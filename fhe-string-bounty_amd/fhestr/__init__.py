@@ -96,7 +96,12 @@ EXPORTS = [
     "fhe_lwe_lincomb_batch", "fhe_last_kernel_ms", "fhe_kernel_times",
     "fhe_params_ksk_len", "fhe_params_bsk_len", "fhe_client_key_create", "fhe_client_key_destroy",
     "fhe_client_encrypt", "fhe_client_decrypt", "fhe_client_gen_server_keys", "fhe_client_secret_keys",
-]
+    "fhe_plan_create", "fhe_plan_destroy", "fhe_plan_input", "fhe_plan_lut", "fhe_plan_lin", "fhe_plan_pbs",
+    "fhe_plan_output", "fhe_plan_finalize", "fhe_plan_info", "fhe_plan_level_info", "fhe_plan_export_level",
+    "fhe_plan_run", "fhe_plan_run_level_slice_dev", "fhe_plan_gather_outputs_dev", "fhe_str_plan_create",
+    "fhe_str_to_upper", "fhe_str_to_lower",
+] + [f"fhe_str_{n}{s}" for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find")
+     for s in ("", "_clear")]
 
 
 def lib() -> C.CDLL:
@@ -143,6 +148,26 @@ def lib() -> C.CDLL:
     sig("fhe_client_decrypt", vp, vp, u32, vp)
     sig("fhe_client_gen_server_keys", vp, vp, vp, i32)
     sig("fhe_client_secret_keys", vp, vp, vp)
+    sig("fhe_plan_create", vp, C.POINTER(vp))
+    sig("fhe_plan_destroy", vp)
+    sig("fhe_plan_input", vp, C.c_uint64, C.POINTER(u32))
+    sig("fhe_plan_lut", vp, vp, C.POINTER(u32))
+    sig("fhe_plan_lin", vp, vp, vp, u32, C.c_int64, C.POINTER(u32))
+    sig("fhe_plan_pbs", vp, u32, u32, C.POINTER(u32))
+    sig("fhe_plan_output", vp, u32)
+    sig("fhe_plan_finalize", vp, u32)
+    sig("fhe_plan_info", vp, C.POINTER(u32))
+    sig("fhe_plan_level_info", vp, u32, C.POINTER(u32))
+    sig("fhe_plan_export_level", vp, u32, vp, vp, vp, vp, vp)
+    sig("fhe_plan_run", vp, vp, vp)
+    sig("fhe_plan_run_level_slice_dev", vp, vp, u32, u32, u32)
+    sig("fhe_plan_gather_outputs_dev", vp, vp, vp)
+    sig("fhe_str_plan_create", vp, C.c_char_p, u32, u32, vp, u32, u32, C.POINTER(vp))
+    for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find"):
+        sig(f"fhe_str_{n}", vp, vp, u32, vp, u32, vp)
+        sig(f"fhe_str_{n}_clear", vp, vp, u32, vp, u32, vp)
+    sig("fhe_str_to_upper", vp, vp, u32, vp)
+    sig("fhe_str_to_lower", vp, vp, u32, vp)
     for name in ("fhe_params_ksk_len", "fhe_params_bsk_len"):
         getattr(L, name).restype = C.c_size_t
         getattr(L, name).argtypes = [PP]
@@ -348,3 +373,173 @@ class ClientKey:
         s = np.zeros(p.n, dtype=np.uint64)
         _check(lib().fhe_client_secret_keys(self._h, _ptr(g), _ptr(s)))
         return g, s
+
+
+class Plan:
+    """A levelised shortint circuit (include/fhestr.h, "plans").  Build with input/lut/lin/pbs/output
+    + finalize, or get a ready-made FheString operation from Plan.string_op."""
+
+    def __init__(self, engine: Engine, handle=None):
+        self.engine = engine
+        self._h = handle or C.c_void_p()
+        if handle is None:
+            _check(lib().fhe_plan_create(engine.handle, C.byref(self._h)))
+
+    @classmethod
+    def string_op(cls, engine: Engine, op: str, a_cap: int, b_cap: int = 0, clear: bytes | None = None,
+                  world: int = 1) -> "Plan":
+        h = C.c_void_p()
+        buf = (C.c_uint8 * max(1, len(clear or b"")))(*(clear or b""))
+        _check(lib().fhe_str_plan_create(engine.handle, op.encode(), a_cap, b_cap, buf,
+                                         len(clear or b""), world, C.byref(h)))
+        return cls(engine, h)
+
+    def close(self):
+        if self._h:
+            lib().fhe_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- building ----
+    def input(self, degree: int | None = None) -> int:
+        node = C.c_uint32()
+        d = self.engine.params.msg_mod - 1 if degree is None else degree
+        _check(lib().fhe_plan_input(self._h, d, C.byref(node)))
+        return node.value
+
+    def lut(self, f) -> int:
+        p = self.engine.params
+        table = np.array([int(f(i)) for i in range(p.msg_mod * p.carry_mod)], dtype=np.uint64)
+        out = C.c_uint32()
+        _check(lib().fhe_plan_lut(self._h, _ptr(table), C.byref(out)))
+        return out.value
+
+    def lin(self, terms, constant: int = 0) -> int:
+        nodes = np.array([t[0] for t in terms] + [0], dtype=np.uint32)
+        coeffs = np.array([t[1] for t in terms] + [0], dtype=np.int32)
+        out = C.c_uint32()
+        _check(lib().fhe_plan_lin(self._h, _ptr(nodes), _ptr(coeffs), len(terms), constant, C.byref(out)))
+        return out.value
+
+    def pbs(self, src: int, lut: int) -> int:
+        out = C.c_uint32()
+        _check(lib().fhe_plan_pbs(self._h, src, lut, C.byref(out)))
+        return out.value
+
+    def output(self, node: int):
+        _check(lib().fhe_plan_output(self._h, node))
+
+    def finalize(self, world: int = 1):
+        _check(lib().fhe_plan_finalize(self._h, world))
+
+    # ---- queries ----
+    def info(self) -> dict:
+        a = (C.c_uint32 * 6)()
+        _check(lib().fhe_plan_info(self._h, a))
+        return dict(zip(("n_inputs", "n_outputs", "n_levels", "n_pbs", "pool_slots", "world"), map(int, a)))
+
+    def level_info(self, level: int) -> dict:
+        a = (C.c_uint32 * 4)()
+        _check(lib().fhe_plan_level_info(self._h, level, a))
+        return dict(zip(("jobs", "base", "per_rank", "terms"), map(int, a)))
+
+    def export_level(self, level: int) -> dict:
+        li = self.level_info(level)
+        off = np.zeros(li["jobs"] + 1, dtype=np.uint32)
+        src = np.zeros(max(li["terms"], 1), dtype=np.uint32)
+        coeff = np.zeros(max(li["terms"], 1), dtype=np.int32)
+        cst = np.zeros(max(li["jobs"], 1), dtype=np.uint64)
+        n_lut = li["jobs"] if level < self.info()["n_levels"] else 0
+        lut = np.zeros(max(n_lut, 1), dtype=np.uint32)
+        _check(lib().fhe_plan_export_level(self._h, level, _ptr(off), _ptr(src), _ptr(coeff), _ptr(cst),
+                                           _ptr(lut) if n_lut else None))
+        return dict(li, off=off, src=src[:li["terms"]], coeff=coeff[:li["terms"]], cst=cst[:li["jobs"]],
+                    lut=lut[:n_lut])
+
+    # ---- execution ----
+    def run(self, inputs) -> np.ndarray:
+        """Single GPU, host buffers."""
+        p = self.engine.params
+        info = self.info()
+        inputs = _u64(inputs).reshape(-1, p.big_size)
+        if inputs.shape[0] != info["n_inputs"]:
+            raise FheError(f"plan expects {info['n_inputs']} input ciphertexts, got {inputs.shape[0]}")
+        out = np.zeros((info["n_outputs"], p.big_size), dtype=np.uint64)
+        _check(lib().fhe_plan_run(self._h, _ptr(inputs) if inputs.size else None, _ptr(out)))
+        return out
+
+    def run_level_slice_dev(self, d_pool: int, level: int, lo: int, hi: int):
+        _check(lib().fhe_plan_run_level_slice_dev(self._h, C.c_void_p(d_pool), level, lo, hi))
+
+    def gather_outputs_dev(self, d_pool: int, d_out: int):
+        _check(lib().fhe_plan_gather_outputs_dev(self._h, C.c_void_p(d_pool), C.c_void_p(d_out)))
+
+
+def blocks_per_char(params: Params) -> int:
+    return 8 // (params.msg_mod.bit_length() - 1)
+
+
+def string_to_blocks(params: Params, s: bytes, cap: int) -> np.ndarray:
+    """Zero padded, little-endian block digits of every character (integer/block_decomposition.rs:119-144)."""
+    if len(s) > cap:
+        raise FheError("string longer than its capacity")
+    bits = params.msg_mod.bit_length() - 1
+    data = np.frombuffer(s.ljust(cap, b"\0"), dtype=np.uint8).astype(np.uint64)
+    return np.stack([(data >> (bits * b)) & (params.msg_mod - 1) for b in range(8 // bits)], axis=1).reshape(-1)
+
+
+def blocks_to_string(params: Params, blocks) -> bytes:
+    bits = params.msg_mod.bit_length() - 1
+    bpc = 8 // bits
+    b = (np.asarray(blocks).reshape(-1, bpc) % params.msg_mod).astype(np.uint64)
+    vals = sum(b[:, i] << (bits * i) for i in range(bpc))
+    return bytes(int(v) for v in vals).rstrip(b"\0")
+
+
+class FheStringOps:
+    """FheString operator surface over one engine (eq/ne/starts_with/ends_with/contains/find/
+    to_upper/to_lower).  Strings are (cap*blocks, kN+1) arrays of big-key LWEs (see string_to_blocks)."""
+
+    def __init__(self, engine: Engine):
+        self.engine = engine
+        self.bpc = blocks_per_char(engine.params)
+
+    def _cap(self, ct):
+        ct = _u64(ct).reshape(-1, self.engine.params.big_size)
+        return ct, ct.shape[0] // self.bpc
+
+    def _binary(self, op, a, b):
+        a, a_cap = self._cap(a)
+        n_dig = 0
+        while (self.engine.params.msg_mod ** n_dig) < a_cap + 1:
+            n_dig += 1
+        n_out = 1 + n_dig if op == "find" else 1
+        out = np.zeros((n_out, self.engine.params.big_size), dtype=np.uint64)
+        if isinstance(b, (bytes, bytearray)):
+            buf = (C.c_uint8 * max(1, len(b)))(*b)
+            _check(getattr(lib(), f"fhe_str_{op}_clear")(self.engine.handle, _ptr(a), a_cap, buf, len(b), _ptr(out)))
+        else:
+            b, b_cap = self._cap(b)
+            _check(getattr(lib(), f"fhe_str_{op}")(self.engine.handle, _ptr(a), a_cap, _ptr(b), b_cap, _ptr(out)))
+        return out
+
+    def eq(self, a, b): return self._binary("eq", a, b)[0]
+    def ne(self, a, b): return self._binary("ne", a, b)[0]
+    def starts_with(self, a, b): return self._binary("starts_with", a, b)[0]
+    def ends_with(self, a, b): return self._binary("ends_with", a, b)[0]
+    def contains(self, a, b): return self._binary("contains", a, b)[0]
+    def find(self, a, b): return self._binary("find", a, b)
+
+    def _unary(self, op, a):
+        a, a_cap = self._cap(a)
+        out = np.zeros_like(a)
+        _check(getattr(lib(), f"fhe_str_{op}")(self.engine.handle, _ptr(a), a_cap, _ptr(out)))
+        return out
+
+    def to_upper(self, a): return self._unary("to_upper", a)
+    def to_lower(self, a): return self._unary("to_lower", a)

@@ -101,6 +101,61 @@ int fhe_last_kernel_ms(fhe_engine *eng, float ms[2]);
  * rotation; *calls = number of calls summed.  Synchronises; reset != 0 clears the record. */
 int fhe_kernel_times(fhe_engine *eng, double total_ms[2], uint32_t *calls, int reset);
 
+/* ---- plans: levelised shortint circuits ----------------------------------------------------- */
+/* A plan records shortint operations (LWE linear combinations and apply_lookup_table) as a DAG and
+ * executes them level by level, one batched KS+PBS launch per level.  It is the batched replacement
+ * of the per-block rayon loops of the reference's integer layer
+ * (integer/server_key/radix_parallel/comparison.rs:10-83, scalar_comparison.rs:104-558).
+ * `world` > 1 pads every level's pool region so that ranks can all-gather equal-sized slices. */
+typedef struct fhe_plan fhe_plan;
+int fhe_plan_create(fhe_engine *eng, fhe_plan **out);
+int fhe_plan_destroy(fhe_plan *plan);
+/* building (before fhe_plan_finalize) */
+int fhe_plan_input(fhe_plan *plan, uint64_t degree, uint32_t *node);
+int fhe_plan_lut(fhe_plan *plan, const uint64_t *table, uint32_t *lut);    /* generate_lookup_table */
+int fhe_plan_lin(fhe_plan *plan, const uint32_t *nodes, const int32_t *coeffs, uint32_t n_terms,
+                 int64_t constant, uint32_t *node);                        /* unchecked add/scalar ops */
+int fhe_plan_pbs(fhe_plan *plan, uint32_t src, uint32_t lut, uint32_t *node); /* apply_lookup_table */
+int fhe_plan_output(fhe_plan *plan, uint32_t node);
+int fhe_plan_finalize(fhe_plan *plan, uint32_t world);
+/* info[6] = {n_inputs, n_outputs, n_levels, n_pbs, pool_slots, world} */
+int fhe_plan_info(const fhe_plan *plan, uint32_t info[6]);
+/* info[4] = {jobs, pool_base, jobs_per_rank, n_terms}; level == n_levels describes the output gather */
+int fhe_plan_level_info(const fhe_plan *plan, uint32_t level, uint32_t info[4]);
+/* CSR description of a level (any pointer may be NULL): off[jobs+1], src/coeff[n_terms] (src = pool
+ * slot), cst[jobs] (already scaled by delta), lut[jobs] */
+int fhe_plan_export_level(const fhe_plan *plan, uint32_t level, uint32_t *off, uint32_t *src,
+                          int32_t *coeff, uint64_t *cst, uint32_t *lut);
+/* single GPU, host buffers: inputs n_inputs x (kN+1), outputs n_outputs x (kN+1) */
+int fhe_plan_run(fhe_plan *plan, const uint64_t *inputs, uint64_t *outputs);
+/* multi-GPU building blocks (device pool of pool_slots big LWEs; inputs live in slots [0, n_inputs)):
+ * run jobs [lo, hi) of one level into their pool slots; gather the outputs from a complete pool. */
+int fhe_plan_run_level_slice_dev(fhe_plan *plan, uint64_t *d_pool, uint32_t level, uint32_t lo, uint32_t hi);
+int fhe_plan_gather_outputs_dev(fhe_plan *plan, const uint64_t *d_pool, uint64_t *d_out);
+
+/* ---- FheString operations --------------------------------------------------------------------- */
+/* An encrypted string = `cap` characters, zero padded, each character 8/log2(msg_mod) big-key LWE
+ * blocks, little endian (integer/block_decomposition.rs:119-144): cap * blocks * (kN+1) u64.
+ * Results decrypt to what the clear-text function gives on the unpadded ASCII strings.
+ * op in {"eq","ne","starts_with","ends_with","contains","find"} (+ "_clear" suffix for a clear
+ * pattern) or {"to_upper","to_lower"}.  Outputs: one 0/1 block; find: found block then
+ * ceil(log_msg_mod(cap+1)) index digits (little endian); case ops: the whole string. */
+int fhe_str_plan_create(fhe_engine *eng, const char *op, uint32_t a_cap, uint32_t b_cap,
+                        const uint8_t *clear, uint32_t clear_len, uint32_t world, fhe_plan **out);
+#define FHE_STR_BINARY_DECL(name)                                                                    \
+    int fhe_str_##name(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const uint64_t *b,       \
+                       uint32_t b_cap, uint64_t *out);                                               \
+    int fhe_str_##name##_clear(fhe_engine *eng, const uint64_t *a, uint32_t a_cap,                  \
+                               const uint8_t *pat, uint32_t pat_len, uint64_t *out);
+FHE_STR_BINARY_DECL(eq)
+FHE_STR_BINARY_DECL(ne)
+FHE_STR_BINARY_DECL(starts_with)
+FHE_STR_BINARY_DECL(ends_with)
+FHE_STR_BINARY_DECL(contains)
+FHE_STR_BINARY_DECL(find)
+int fhe_str_to_upper(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
+int fhe_str_to_lower(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
+
 /* ---- client side (CPU): keys, encryption, decryption ---------------------------------------- */
 /* ClientKey::new / encrypt / decrypt_message_and_carry / ServerKey::new of the reference
  * (shortint/engine/client_side.rs:13-128, shortint/client_key/mod.rs:281-337,

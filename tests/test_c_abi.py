@@ -13,7 +13,10 @@ from conftest import ROOT, to_fhestr_params
 def _declared_functions():
     text = open(os.path.join(ROOT, "include", "fhestr.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(fhe_[a-z0-9_]+)\s*\(", text)))
+    names = set(re.findall(r"\b(fhe_[a-z0-9_]+)\s*\(", text))
+    for n in re.findall(r"^FHE_STR_BINARY_DECL\((\w+)\)", text, flags=re.M):   # macro-declared pairs
+        names |= {f"fhe_str_{n}", f"fhe_str_{n}_clear"}
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():

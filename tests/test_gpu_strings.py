@@ -1,0 +1,140 @@
+"""FheString operations on the GPU vs clear-text Python string semantics (the reference's notion of
+correctness: decrypt(op(enc(x))) == clear_op(x), integer/.../tests_cases_comparisons.rs:33-39,
+docs/tutorials/ascii_fhe_string.md:141-152), plus plan-level parity with the CPU oracle."""
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import gpu_engine, keyset
+from plan_oracle import export_plan, run_with_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _enc(ks, s: bytes, cap: int):
+    import fhestr
+    blocks = fhestr.string_to_blocks(gpu_engine(ks).params, s, cap)
+    return ks.ck.encrypt_many(blocks)
+
+
+def _dec(ks, cts):
+    return ks.ck.decrypt_many(np.asarray(cts).reshape(-1, ks.params.big_size))
+
+
+def _ops(ks):
+    import fhestr
+    return fhestr.FheStringOps(gpu_engine(ks))
+
+
+CASES = [(b"hello", b"hello"), (b"hello", b"hellp"), (b"hello", b"hell"), (b"", b""), (b"", b"a"),
+         (b"abcdefgh", b"abcdefgh"), (b"Zz", b"zZ")]
+
+
+@pytest.mark.parametrize("a,b", CASES)
+def test_eq_ne_encrypted_and_clear(toy_k1, a, b):
+    ops = _ops(toy_k1)
+    ea, eb = _enc(toy_k1, a, 8), _enc(toy_k1, b, 8)
+    assert _dec(toy_k1, ops.eq(ea, eb))[0] == int(a == b)
+    assert _dec(toy_k1, ops.ne(ea, eb))[0] == int(a != b)
+    assert _dec(toy_k1, ops.eq(ea, b))[0] == int(a == b)
+    assert _dec(toy_k1, ops.ne(ea, b))[0] == int(a != b)
+
+
+def test_eq_different_capacities(toy_k1):
+    ops = _ops(toy_k1)
+    assert _dec(toy_k1, ops.eq(_enc(toy_k1, b"abc", 8), _enc(toy_k1, b"abc", 4)))[0] == 1
+    assert _dec(toy_k1, ops.eq(_enc(toy_k1, b"abcde", 8), _enc(toy_k1, b"abc", 4)))[0] == 0
+    assert _dec(toy_k1, ops.eq(_enc(toy_k1, b"abc", 4), b"abcdefgh"))[0] == 0  # clear longer than capacity
+
+
+PATTERN_CASES = [(b"hello wd", b"hell"), (b"hello wd", b"o wd"), (b"hello wd", b"lo"), (b"hello wd", b"xyz"),
+                 (b"hello", b"lo"), (b"hello", b""), (b"", b""), (b"", b"a"), (b"aaa", b"aa"), (b"abab", b"bab"),
+                 (b"ab", b"abc"), (b"hello", b"hello"), (b"hellohel", b"hel")]
+
+
+@pytest.mark.parametrize("s,pat", PATTERN_CASES)
+def test_starts_ends_contains(toy_k1, s, pat):
+    ops = _ops(toy_k1)
+    es, ep = _enc(toy_k1, s, 8), _enc(toy_k1, pat, 4 if len(pat) <= 4 else 8)
+    for name, want in (("starts_with", s.startswith(pat)), ("ends_with", s.endswith(pat)), ("contains", pat in s)):
+        assert _dec(toy_k1, getattr(ops, name)(es, ep))[0] == int(want), (name, "encrypted pattern")
+        assert _dec(toy_k1, getattr(ops, name)(es, pat))[0] == int(want), (name, "clear pattern")
+
+
+@pytest.mark.parametrize("s,pat", PATTERN_CASES)
+def test_find(toy_k1, s, pat):
+    ops = _ops(toy_k1)
+    es, ep = _enc(toy_k1, s, 8), _enc(toy_k1, pat, 4 if len(pat) <= 4 else 8)
+    want = s.find(pat)
+    for p in (ep, pat):
+        out = _dec(toy_k1, ops.find(es, p))
+        found, digits = out[0], out[1:]
+        assert found == int(want >= 0)
+        if want >= 0:
+            assert sum(int(d) * 4**i for i, d in enumerate(digits)) == want
+
+
+@pytest.mark.parametrize("s", [b"Hello Wd", b"az AZ@[`", b"", b"{}09\x7f\x01"])
+def test_case_conversion(toy_k1, s):
+    import fhestr
+    ops = _ops(toy_k1)
+    es = _enc(toy_k1, s, 8)
+    P = gpu_engine(toy_k1).params
+    assert fhestr.blocks_to_string(P, _dec(toy_k1, ops.to_upper(es))) == s.upper().rstrip(b"\0")
+    assert fhestr.blocks_to_string(P, _dec(toy_k1, ops.to_lower(es))) == s.lower().rstrip(b"\0")
+
+
+def test_plan_matches_oracle_execution(toy_k1):
+    """Same plan, same inputs: GPU executor vs the oracle stepping through the exported levels."""
+    import fhestr
+    eng = gpu_engine(toy_k1)
+    plan = fhestr.Plan.string_op(eng, "contains", 8, 4)
+    ex = export_plan(plan)
+    lut_ids = sorted({int(i) for lv in ex["levels"][:-1] for i in lv["lut"]})
+    luts = {i: eng.download_lut(i) for i in lut_ids}
+    inputs = np.concatenate([_enc(toy_k1, b"abcabd", 8), _enc(toy_k1, b"abd", 4)])
+    got = plan.run(inputs)
+    want = run_with_oracle(ex, inputs, toy_k1.sk, luts)
+    assert np.array_equal(_dec(toy_k1, got), _dec(toy_k1, want))
+    assert _dec(toy_k1, got)[0] == 1
+
+
+def test_plan_pbs_counts_match_survey():
+    """eq enc-enc on 256 chars = 1099 KS+PBS in 4 levels; enc-clear = 551."""
+    import fhestr
+    ks = keyset(O.TOY_K1)
+    eng = gpu_engine(ks)
+    info = fhestr.Plan.string_op(eng, "eq", 256, 256).info()
+    assert (info["n_pbs"], info["n_levels"]) == (1099, 4)
+    info = fhestr.Plan.string_op(eng, "eq_clear", 256, 0, b"x" * 200).info()
+    assert (info["n_pbs"], info["n_levels"]) == (551, 4)
+
+
+def test_p22_eq_256_chars(p22):
+    """BASELINE.json config 3: 256-char padded strings, equal / differing at one position."""
+    ops = _ops(p22)
+    rng = np.random.default_rng(0x5EED0003)
+    a = bytes(rng.integers(0x20, 0x7F, size=200, dtype=np.uint8))
+    pos = int(rng.integers(0, 200))
+    b = a[:pos] + bytes([a[pos] ^ 1]) + a[pos + 1:]
+    ea, eb = _enc(p22, a, 256), _enc(p22, b, 256)
+    assert _dec(p22, ops.eq(ea, _enc(p22, a, 256)))[0] == 1
+    assert _dec(p22, ops.eq(ea, eb))[0] == 0
+    assert _dec(p22, ops.ne(ea, eb))[0] == 1
+    assert _dec(p22, ops.eq(ea, a))[0] == 1
+    assert _dec(p22, ops.eq(ea, b))[0] == 0
+
+
+def test_p22_contains_find_16_in_256(p22):
+    """BASELINE.json config 4 (single GPU leg): 16-char encrypted pattern in a 256-char haystack."""
+    ops = _ops(p22)
+    rng = np.random.default_rng(0x5EED0004)
+    hay = bytes(rng.integers(0x61, 0x7B, size=256, dtype=np.uint8))
+    off = int(rng.integers(0, 240))
+    pat = hay[off: off + 16]
+    eh = _enc(p22, hay, 256)
+    out = _dec(p22, ops.find(eh, _enc(p22, pat, 16)))
+    assert out[0] == 1 and sum(int(d) * 4**i for i, d in enumerate(out[1:])) == hay.find(pat)
+    absent = b"0123456789ABCDEF"
+    assert _dec(p22, ops.contains(eh, _enc(p22, absent, 16)))[0] == 0
+    assert _dec(p22, ops.contains(eh, _enc(p22, pat, 16)))[0] == 1
