@@ -79,7 +79,7 @@ int fhe_lut_generate(fhe_engine* eng, const uint64_t* table, uint32_t* lut_id, u
     std::vector<uint64_t> acc;
     uint64_t deg = eng->impl->fill_accumulator(table, acc);
     if (degree) *degree = deg;
-    return eng->impl->lut_upload(acc.data(), lut_id);
+    return eng->impl->lut_upload_dedup(acc, lut_id);
     API_END
 }
 
@@ -182,8 +182,25 @@ int fhe_plan_create(fhe_engine* eng, fhe_plan** out) {
     CHECK_PTR(out);
     *out = nullptr;
     CHECK_PTR(eng);
-    *out = new fhe_plan{new fhe::Circuit(eng->impl), false};
+    *out = new fhe_plan{new fhe::Circuit(eng->impl->p, eng->impl), false};
     return 0;
+    API_END
+}
+
+int fhe_plan_create_offline(const fhe_params_t* params, fhe_plan** out) {
+    API_BEGIN
+    CHECK_PTR(out);
+    *out = nullptr;
+    CHECK_PTR(params);
+    *out = new fhe_plan{new fhe::Circuit(*params, nullptr), false};
+    return 0;
+    API_END
+}
+
+int fhe_engine_set_stream(fhe_engine* eng, void* hip_stream) {
+    API_BEGIN
+    CHECK_PTR(eng);
+    return eng->impl->set_stream((hipStream_t)hip_stream);
     API_END
 }
 
@@ -259,19 +276,52 @@ int fhe_plan_finalize(fhe_plan* p, uint32_t world) {
     API_END
 }
 
-int fhe_str_plan_create(fhe_engine* eng, const char* op, uint32_t a_cap, uint32_t b_cap,
-                        const uint8_t* clear, uint32_t clear_len, uint32_t world, fhe_plan** out) {
-    API_BEGIN
-    CHECK_PTR(out);
-    *out = nullptr;
-    CHECK_PTR(eng); CHECK_PTR(op);
-    fhe::Circuit* c = new fhe::Circuit(eng->impl);
+static int str_plan(const fhe_params_t& params, fhe::Engine* eng, const char* op, uint32_t a_cap,
+                    uint32_t b_cap, const uint8_t* clear, uint32_t clear_len, uint32_t world, fhe_plan** out) {
+    fhe::Circuit* c = new fhe::Circuit(params, eng);
     if (fhe::build_string_op(*c, op, a_cap, b_cap, clear, clear_len) || c->finalize(world)) {
         delete c;
         return 1;
     }
     *out = new fhe_plan{c, true};
     return 0;
+}
+
+int fhe_str_plan_create_offline(const fhe_params_t* params, const char* op, uint32_t a_cap, uint32_t b_cap,
+                                const uint8_t* clear, uint32_t clear_len, uint32_t world, fhe_plan** out) {
+    API_BEGIN
+    CHECK_PTR(out);
+    *out = nullptr;
+    CHECK_PTR(params); CHECK_PTR(op);
+    return str_plan(*params, nullptr, op, a_cap, b_cap, clear, clear_len, world, out);
+    API_END
+}
+
+int fhe_plan_lut_count(const fhe_plan* p, uint32_t* count) {
+    API_BEGIN
+    CHECK_PTR(p); CHECK_PTR(count);
+    *count = p->c->n_luts();
+    return 0;
+    API_END
+}
+
+int fhe_plan_export_lut(const fhe_plan* p, uint32_t lut, uint64_t* accumulator) {
+    API_BEGIN
+    CHECK_PTR(p); CHECK_PTR(accumulator);
+    if (lut >= p->c->n_luts()) return fail("bad plan LUT id");
+    const auto& acc = p->c->lut_accumulator(lut);
+    std::copy(acc.begin(), acc.end(), accumulator);
+    return 0;
+    API_END
+}
+
+int fhe_str_plan_create(fhe_engine* eng, const char* op, uint32_t a_cap, uint32_t b_cap,
+                        const uint8_t* clear, uint32_t clear_len, uint32_t world, fhe_plan** out) {
+    API_BEGIN
+    CHECK_PTR(out);
+    *out = nullptr;
+    CHECK_PTR(eng); CHECK_PTR(op);
+    return str_plan(eng->impl->p, eng->impl, op, a_cap, b_cap, clear, clear_len, world, out);
     API_END
 }
 

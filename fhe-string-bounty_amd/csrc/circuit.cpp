@@ -63,19 +63,18 @@ uint32_t Circuit::lut(const std::vector<uint64_t>& table) {
     if (it != lut_cache_.end()) return it->second;
     if (table.size() != total_modulus()) { error_ = "lut: table size must be msg_mod*carry_mod"; return 0; }
     std::vector<uint64_t> acc;
-    eng_->fill_accumulator(table.data(), acc);
-    uint32_t id = 0;
-    if (eng_->lut_upload(acc.data(), &id)) { error_ = "lut upload failed: " + g_last_error; return 0; }
+    fill_accumulator(p_, table.data(), acc);
+    const uint32_t id = (uint32_t)lut_accs_.size();
+    lut_accs_.push_back(acc);
+    lut_tables_.push_back(table);
     lut_cache_[table] = id;
     return id;
 }
 
 uint32_t Circuit::pbs(uint32_t id, uint32_t lut_id) {
     if (id >= nodes_.size()) { error_ = "pbs: bad node id"; return 0; }
-    const std::vector<uint64_t>* table = nullptr;
-    for (auto& kv : lut_cache_)
-        if (kv.second == lut_id) table = &kv.first;
-    if (!table) { error_ = "pbs: LUT was not created through this circuit"; return 0; }
+    if (lut_id >= lut_tables_.size()) { error_ = "pbs: LUT was not created through this plan"; return 0; }
+    const std::vector<uint64_t>* table = &lut_tables_[lut_id];
     uint32_t src = id;
     if (nodes_[id].kind != Node::LIN) src = lin({{id, 1}});
     const Node& s = nodes_[src];
@@ -153,13 +152,17 @@ int Circuit::finalize(uint32_t world) {
         build_csr(lv, srcs);
     }
     build_csr(out_, outputs_);
-    return upload_meta();
+    return eng_ ? upload_meta() : 0;
 }
 
 static size_t align8(size_t x) { return (x + 7) / 8 * 8; }
 
 int Circuit::upload_meta() {
     if (eng_->use()) return 1;
+    // plan-local LUT ids -> engine LUT ids (identical accumulators share one resident copy)
+    std::vector<uint32_t> engine_id(lut_accs_.size());
+    for (size_t i = 0; i < lut_accs_.size(); i++)
+        if (eng_->lut_upload_dedup(lut_accs_[i], &engine_id[i])) return 1;
     size_t total = 0;
     auto place = [&](Level& lv) {
         lv.meta_off = total;   total += align8(lv.off.size() * 4);
@@ -176,7 +179,9 @@ int Circuit::upload_meta() {
         std::memcpy(host.data() + lv.meta_src, lv.src.data(), lv.src.size() * 4);
         std::memcpy(host.data() + lv.meta_coeff, lv.coeff.data(), lv.coeff.size() * 4);
         std::memcpy(host.data() + lv.meta_cst, lv.cst.data(), lv.cst.size() * 8);
-        std::memcpy(host.data() + lv.meta_lut, lv.lut.data(), lv.lut.size() * 4);
+        std::vector<uint32_t> ids(lv.lut.size());
+        for (size_t i = 0; i < ids.size(); i++) ids[i] = engine_id[lv.lut[i]];
+        std::memcpy(host.data() + lv.meta_lut, ids.data(), ids.size() * 4);
     };
     for (auto& lv : levels_) fill(lv);
     fill(out_);
@@ -186,7 +191,7 @@ int Circuit::upload_meta() {
     HIP_TRY(hipStreamSynchronize(eng_->stream));
     size_t max_jobs = 1;
     for (auto& lv : levels_) max_jobs = std::max(max_jobs, (size_t)lv.per_rank);
-    const size_t big = (size_t)eng_->p.k * eng_->p.N + 1;
+    const size_t big = (size_t)p_.k * p_.N + 1;
     if (stage_cap_ < max_jobs * big * 8) {
         if (d_stage_) HIP_TRY(hipFree(d_stage_));
         d_stage_ = nullptr;
@@ -197,13 +202,14 @@ int Circuit::upload_meta() {
 }
 
 int Circuit::run_level_slice(uint64_t* d_pool, uint32_t l, uint32_t lo, uint32_t hi) {
+    if (!eng_) return fail("offline plan: no engine bound (there is no CPU execution path)");
     if (l >= levels_.size()) return fail("bad level");
     const Level& lv = levels_[l];
     hi = std::min<uint32_t>(hi, (uint32_t)lv.jobs.size());
     if (lo >= hi) return 0;
     if (hi - lo > lv.per_rank && world_ > 1) return fail("slice larger than the per-rank region");
     if (eng_->use()) return 1;
-    const size_t big = (size_t)eng_->p.k * eng_->p.N + 1;
+    const size_t big = (size_t)p_.k * p_.N + 1;
     if ((size_t)(hi - lo) * big * 8 > stage_cap_) {
         if (d_stage_) HIP_TRY(hipFree(d_stage_));
         d_stage_ = nullptr;
@@ -221,6 +227,7 @@ int Circuit::run_level_slice(uint64_t* d_pool, uint32_t l, uint32_t lo, uint32_t
 }
 
 int Circuit::gather_outputs(const uint64_t* d_pool, uint64_t* d_out) {
+    if (!eng_) return fail("offline plan: no engine bound (there is no CPU execution path)");
     if (eng_->use()) return 1;
     const unsigned char* m = reinterpret_cast<const unsigned char*>(d_meta_);
     return eng_->lincomb_dev(d_pool, reinterpret_cast<const uint32_t*>(m + out_.meta_off),
@@ -230,9 +237,10 @@ int Circuit::gather_outputs(const uint64_t* d_pool, uint64_t* d_out) {
 }
 
 int Circuit::run_host(const uint64_t* inputs, uint64_t* outputs) {
+    if (!eng_) return fail("offline plan: no engine bound (there is no CPU execution path)");
     if (eng_->use()) return 1;
     if (world_ != 1) return fail("run_host needs a plan finalised for world = 1");
-    const size_t big = (size_t)eng_->p.k * eng_->p.N + 1;
+    const size_t big = (size_t)p_.k * p_.N + 1;
     if (!d_own_pool_) HIP_TRY(hipMalloc((void**)&d_own_pool_, (size_t)std::max<uint32_t>(pool_slots_, 1) * big * 8));
     if (!d_own_out_) HIP_TRY(hipMalloc((void**)&d_own_out_, (size_t)std::max<uint32_t>(n_outputs(), 1) * big * 8));
     if (n_inputs_)
@@ -246,6 +254,7 @@ int Circuit::run_host(const uint64_t* inputs, uint64_t* outputs) {
 }
 
 Circuit::~Circuit() {
+    if (!eng_) return;
     (void)hipSetDevice(eng_->device);
     if (d_meta_) (void)hipFree(d_meta_);
     if (d_stage_) (void)hipFree(d_stage_);

@@ -49,7 +49,8 @@ struct Node {
 
 class Circuit {
 public:
-    explicit Circuit(Engine* eng) : eng_(eng) {}
+    // eng may be null: the plan can then be built, finalised and exported, but not run
+    Circuit(const fhe_params_t& params, Engine* eng) : p_(params), eng_(eng) {}
 
     uint32_t input(uint64_t degree);                             // next input ciphertext
     // degree_override >= 0 replaces the conservative degree bound (caller knows better)
@@ -67,8 +68,11 @@ public:
     }
     void output(uint32_t node) { outputs_.push_back(node); }
 
-    uint32_t total_modulus() const { return eng_->p.msg_mod * eng_->p.carry_mod; }
-    uint32_t msg_modulus() const { return eng_->p.msg_mod; }
+    uint32_t total_modulus() const { return p_.msg_mod * p_.carry_mod; }
+    uint32_t msg_modulus() const { return p_.msg_mod; }
+    const fhe_params_t& params() const { return p_; }
+    uint32_t n_luts() const { return (uint32_t)lut_accs_.size(); }
+    const std::vector<uint64_t>& lut_accumulator(uint32_t id) const { return lut_accs_[id]; }
     const Node& node(uint32_t id) const { return nodes_[id]; }
     bool failed() const { return !error_.empty(); }
     const std::string& error() const { return error_; }
@@ -106,7 +110,10 @@ private:
     void flatten(uint32_t node, int64_t mult, std::map<uint32_t, int64_t>& acc, int64_t& cst) const;
     void build_csr(Level& lv, const std::vector<uint32_t>& lin_nodes);
 
+    fhe_params_t p_;
     Engine* eng_;
+    std::vector<std::vector<uint64_t>> lut_accs_;     // accumulator of every plan-local LUT id
+    std::vector<std::vector<uint64_t>> lut_tables_;   // its clear table
     std::vector<Node> nodes_;
     std::vector<uint32_t> outputs_;
     std::map<std::vector<uint64_t>, uint32_t> lut_cache_;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -15,10 +16,15 @@ int fail(const std::string& msg);
 
 struct BrVariant;
 
+// fill_accumulator: shortint/engine/mod.rs:72-128 (host side, no device needed)
+uint64_t fill_accumulator(const fhe_params_t& p, const uint64_t* table, std::vector<uint64_t>& acc);
+
 struct Engine {
     fhe_params_t p{};
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::map<std::vector<uint64_t>, uint32_t> lut_dedup;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // scratch triple (unused slots of the ring below)
     std::vector<hipEvent_t> ring;   // 3 events per recorded ks_pbs call
     size_t ring_used = 0;           // calls recorded since the last reset
@@ -42,7 +48,9 @@ struct Engine {
     int use();
     int set_variant(int logR);
     int load_keys(const uint64_t* bsk_std, const uint64_t* ksk);
-    uint64_t fill_accumulator(const uint64_t* table, std::vector<uint64_t>& acc) const;
+    uint64_t fill_accumulator(const uint64_t* table, std::vector<uint64_t>& acc) const { return fhe::fill_accumulator(p, table, acc); }
+    int lut_upload_dedup(const std::vector<uint64_t>& acc, uint32_t* id);   // same contents -> same id
+    int set_stream(hipStream_t s);   // launch on a caller-owned stream (e.g. the framework's current stream)
     int lut_upload(const uint64_t* acc, uint32_t* id);
     int lut_download(uint32_t id, uint64_t* acc);
     int ensure_batch(uint32_t count);

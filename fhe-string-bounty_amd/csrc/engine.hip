@@ -101,7 +101,8 @@ int Engine::create(const fhe_params_t& p, int device, Engine** out) {
     e->p = p;
     e->device = device;
     e->variant = v;
-    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    e->stream = e->own_stream;
     for (auto& ev : e->ev) HIP_TRY(hipEventCreate(&ev));
     *out = e;
     return 0;
@@ -115,7 +116,22 @@ Engine::~Engine() {
     rel(d_pool); rel(d_meta);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ring) if (e) (void)hipEventDestroy(e);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+int Engine::set_stream(hipStream_t s) {
+    if (use()) return 1;
+    HIP_TRY(hipStreamSynchronize(stream));
+    stream = s ? s : own_stream;
+    return 0;
+}
+
+int Engine::lut_upload_dedup(const std::vector<uint64_t>& acc, uint32_t* id) {
+    auto it = lut_dedup.find(acc);
+    if (it != lut_dedup.end()) { *id = it->second; return 0; }
+    if (lut_upload(acc.data(), id)) return 1;
+    lut_dedup[acc] = *id;
+    return 0;
 }
 
 int Engine::use() { HIP_TRY(hipSetDevice(device)); return 0; }
@@ -166,7 +182,7 @@ int Engine::load_keys(const uint64_t* bsk_std, const uint64_t* ksk) {
 }
 
 // fill_accumulator: shortint/engine/mod.rs:72-128
-uint64_t Engine::fill_accumulator(const uint64_t* table, std::vector<uint64_t>& acc) const {
+uint64_t fill_accumulator(const fhe_params_t& p, const uint64_t* table, std::vector<uint64_t>& acc) {
     const uint32_t N = p.N, k = p.k;
     acc.assign((size_t)(k + 1) * N, 0);
     uint64_t* body = acc.data() + (size_t)k * N;

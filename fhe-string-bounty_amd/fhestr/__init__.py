@@ -99,7 +99,8 @@ EXPORTS = [
     "fhe_plan_create", "fhe_plan_destroy", "fhe_plan_input", "fhe_plan_lut", "fhe_plan_lin", "fhe_plan_pbs",
     "fhe_plan_output", "fhe_plan_finalize", "fhe_plan_info", "fhe_plan_level_info", "fhe_plan_export_level",
     "fhe_plan_run", "fhe_plan_run_level_slice_dev", "fhe_plan_gather_outputs_dev", "fhe_str_plan_create",
-    "fhe_str_to_upper", "fhe_str_to_lower",
+    "fhe_str_to_upper", "fhe_str_to_lower", "fhe_plan_create_offline", "fhe_str_plan_create_offline",
+    "fhe_plan_lut_count", "fhe_plan_export_lut", "fhe_engine_set_stream",
 ] + [f"fhe_str_{n}{s}" for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find")
      for s in ("", "_clear")]
 
@@ -150,6 +151,11 @@ def lib() -> C.CDLL:
     sig("fhe_client_secret_keys", vp, vp, vp)
     sig("fhe_plan_create", vp, C.POINTER(vp))
     sig("fhe_plan_destroy", vp)
+    sig("fhe_plan_create_offline", PP, C.POINTER(vp))
+    sig("fhe_str_plan_create_offline", PP, C.c_char_p, u32, u32, vp, u32, u32, C.POINTER(vp))
+    sig("fhe_plan_lut_count", vp, C.POINTER(u32))
+    sig("fhe_plan_export_lut", vp, u32, vp)
+    sig("fhe_engine_set_stream", vp, vp)
     sig("fhe_plan_input", vp, C.c_uint64, C.POINTER(u32))
     sig("fhe_plan_lut", vp, vp, C.POINTER(u32))
     sig("fhe_plan_lin", vp, vp, vp, u32, C.c_int64, C.POINTER(u32))
@@ -220,6 +226,10 @@ class Engine:
 
     def synchronize(self):
         _check(lib().fhe_engine_synchronize(self._h))
+
+    def set_stream(self, hip_stream: int | None):
+        """Launch on a caller-owned stream (e.g. torch.cuda.current_stream().cuda_stream)."""
+        _check(lib().fhe_engine_set_stream(self._h, C.c_void_p(hip_stream or 0)))
 
     def load_keys(self, bsk_std, ksk):
         p = self.params
@@ -379,20 +389,40 @@ class Plan:
     """A levelised shortint circuit (include/fhestr.h, "plans").  Build with input/lut/lin/pbs/output
     + finalize, or get a ready-made FheString operation from Plan.string_op."""
 
-    def __init__(self, engine: Engine, handle=None):
+    def __init__(self, engine: "Engine | None", handle=None, params: Params | None = None):
+        """engine=None builds an offline plan (exportable, not runnable) from `params`."""
         self.engine = engine
+        self.params = engine.params if engine is not None else params
         self._h = handle or C.c_void_p()
         if handle is None:
-            _check(lib().fhe_plan_create(engine.handle, C.byref(self._h)))
+            if engine is not None:
+                _check(lib().fhe_plan_create(engine.handle, C.byref(self._h)))
+            else:
+                _check(lib().fhe_plan_create_offline(C.byref(params.c()), C.byref(self._h)))
 
     @classmethod
-    def string_op(cls, engine: Engine, op: str, a_cap: int, b_cap: int = 0, clear: bytes | None = None,
-                  world: int = 1) -> "Plan":
+    def string_op(cls, engine: "Engine | None", op: str, a_cap: int, b_cap: int = 0,
+                  clear: bytes | None = None, world: int = 1, params: Params | None = None) -> "Plan":
         h = C.c_void_p()
         buf = (C.c_uint8 * max(1, len(clear or b"")))(*(clear or b""))
-        _check(lib().fhe_str_plan_create(engine.handle, op.encode(), a_cap, b_cap, buf,
-                                         len(clear or b""), world, C.byref(h)))
-        return cls(engine, h)
+        if engine is not None:
+            _check(lib().fhe_str_plan_create(engine.handle, op.encode(), a_cap, b_cap, buf,
+                                             len(clear or b""), world, C.byref(h)))
+        else:
+            _check(lib().fhe_str_plan_create_offline(C.byref(params.c()), op.encode(), a_cap, b_cap, buf,
+                                                     len(clear or b""), world, C.byref(h)))
+        return cls(engine, h, params)
+
+    def export_luts(self) -> dict:
+        """{plan-local LUT id: accumulator}."""
+        n = C.c_uint32()
+        _check(lib().fhe_plan_lut_count(self._h, C.byref(n)))
+        out = {}
+        for i in range(n.value):
+            acc = np.zeros(self.params.glwe_len, dtype=np.uint64)
+            _check(lib().fhe_plan_export_lut(self._h, i, _ptr(acc)))
+            out[i] = acc
+        return out
 
     def close(self):
         if self._h:
@@ -408,12 +438,12 @@ class Plan:
     # ---- building ----
     def input(self, degree: int | None = None) -> int:
         node = C.c_uint32()
-        d = self.engine.params.msg_mod - 1 if degree is None else degree
+        d = self.params.msg_mod - 1 if degree is None else degree
         _check(lib().fhe_plan_input(self._h, d, C.byref(node)))
         return node.value
 
     def lut(self, f) -> int:
-        p = self.engine.params
+        p = self.params
         table = np.array([int(f(i)) for i in range(p.msg_mod * p.carry_mod)], dtype=np.uint64)
         out = C.c_uint32()
         _check(lib().fhe_plan_lut(self._h, _ptr(table), C.byref(out)))
@@ -464,7 +494,7 @@ class Plan:
     # ---- execution ----
     def run(self, inputs) -> np.ndarray:
         """Single GPU, host buffers."""
-        p = self.engine.params
+        p = self.params
         info = self.info()
         inputs = _u64(inputs).reshape(-1, p.big_size)
         if inputs.shape[0] != info["n_inputs"]:

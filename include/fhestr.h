@@ -56,6 +56,10 @@ int fhe_engine_params(const fhe_engine *eng, fhe_params_t *out);
 int fhe_engine_load_keys(fhe_engine *eng, const uint64_t *bsk_std, const uint64_t *ksk);
 /* The engine's HIP stream (hipStream_t) so callers can order their own work against it. */
 void *fhe_engine_stream(fhe_engine *eng);
+/* Launch on a caller-owned hipStream_t instead (NULL = back to the engine's own stream), e.g. the
+ * framework stream RCCL collectives are enqueued on, so no host synchronisation is needed between
+ * a level's kernels and its all-gather. */
+int fhe_engine_set_stream(fhe_engine *eng, void *hip_stream);
 int fhe_engine_synchronize(fhe_engine *eng);
 /* Choose the blind-rotation variant: points per thread = 2^log2_points (0 = automatic). */
 int fhe_engine_set_variant(fhe_engine *eng, int log2_points);
@@ -109,6 +113,9 @@ int fhe_kernel_times(fhe_engine *eng, double total_ms[2], uint32_t *calls, int r
  * `world` > 1 pads every level's pool region so that ranks can all-gather equal-sized slices. */
 typedef struct fhe_plan fhe_plan;
 int fhe_plan_create(fhe_engine *eng, fhe_plan **out);
+/* Engine-less plan: can be built, finalised and exported (levels, LUT accumulators) on a host
+ * without a GPU -- used by planners and checkers; every run entry point refuses it. */
+int fhe_plan_create_offline(const fhe_params_t *params, fhe_plan **out);
 int fhe_plan_destroy(fhe_plan *plan);
 /* building (before fhe_plan_finalize) */
 int fhe_plan_input(fhe_plan *plan, uint64_t degree, uint32_t *node);
@@ -127,6 +134,9 @@ int fhe_plan_level_info(const fhe_plan *plan, uint32_t level, uint32_t info[4]);
 int fhe_plan_export_level(const fhe_plan *plan, uint32_t level, uint32_t *off, uint32_t *src,
                           int32_t *coeff, uint64_t *cst, uint32_t *lut);
 /* single GPU, host buffers: inputs n_inputs x (kN+1), outputs n_outputs x (kN+1) */
+/* plan-local LUT ids (the `lut` arrays above) and their accumulators ((k+1)*N u64) */
+int fhe_plan_lut_count(const fhe_plan *plan, uint32_t *count);
+int fhe_plan_export_lut(const fhe_plan *plan, uint32_t lut, uint64_t *accumulator);
 int fhe_plan_run(fhe_plan *plan, const uint64_t *inputs, uint64_t *outputs);
 /* multi-GPU building blocks (device pool of pool_slots big LWEs; inputs live in slots [0, n_inputs)):
  * run jobs [lo, hi) of one level into their pool slots; gather the outputs from a complete pool. */
@@ -142,6 +152,9 @@ int fhe_plan_gather_outputs_dev(fhe_plan *plan, const uint64_t *d_pool, uint64_t
  * ceil(log_msg_mod(cap+1)) index digits (little endian); case ops: the whole string. */
 int fhe_str_plan_create(fhe_engine *eng, const char *op, uint32_t a_cap, uint32_t b_cap,
                         const uint8_t *clear, uint32_t clear_len, uint32_t world, fhe_plan **out);
+int fhe_str_plan_create_offline(const fhe_params_t *params, const char *op, uint32_t a_cap,
+                                uint32_t b_cap, const uint8_t *clear, uint32_t clear_len,
+                                uint32_t world, fhe_plan **out);
 #define FHE_STR_BINARY_DECL(name)                                                                    \
     int fhe_str_##name(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const uint64_t *b,       \
                        uint32_t b_cap, uint64_t *out);                                               \

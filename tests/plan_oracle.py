@@ -1,14 +1,8 @@
-"""Checker: execute an exported plan (fhe_plan_export_level) with the CPU oracle, optionally sharded
-over torch.distributed ranks exactly the way the GPU executor shards it.  Test infrastructure."""
+"""Checker backend: execute a plan's exported levels (fhe_plan_export_level / _export_lut) with the
+CPU oracle, optionally all-gathering through torch.distributed (gloo).  Test infrastructure."""
 import numpy as np
 
 import oracle as O
-
-
-def export_plan(plan):
-    info = plan.info()
-    levels = [plan.export_level(l) for l in range(info["n_levels"] + 1)]
-    return dict(info=info, levels=levels)
 
 
 def lincomb(pool, lv, jobs):
@@ -22,24 +16,42 @@ def lincomb(pool, lv, jobs):
     return out
 
 
-def run_with_oracle(exported, inputs, sk: O.ServerKey, lut_tables, rank=0, world=1, all_gather=None):
-    """lut_tables: {lut_id: accumulator}.  all_gather(region_rows, own_rows) fills region in place."""
-    info = exported["info"]
-    p = sk.params
-    pool = np.zeros((info["pool_slots"], p.big_size), dtype=np.uint64)
-    pool[: info["n_inputs"]] = inputs
-    for lv in exported["levels"][:-1]:
-        per = lv["per_rank"]
-        lo, hi = rank * per, min(lv["jobs"], (rank + 1) * per)
-        jobs = list(range(lo, hi)) if lo < hi else []
-        if jobs:
-            staged = lincomb(pool, lv, jobs)
-            ids = sorted(set(int(lv["lut"][j]) for j in jobs))
-            luts = np.stack([lut_tables[i] for i in ids])
-            idx = np.array([ids.index(int(lv["lut"][j])) for j in jobs], dtype=np.uint32)
-            pool[lv["base"] + lo: lv["base"] + hi] = sk.apply_lookup_table_batch(staged, luts, idx)
-        if world > 1:
-            region = pool[lv["base"]: lv["base"] + per * world]
-            all_gather(region, region[rank * per: (rank + 1) * per].copy())
-    out_lv = exported["levels"][-1]
-    return lincomb(pool, out_lv, list(range(out_lv["jobs"])))
+class OracleBackend:
+    def __init__(self, plan, sk: O.ServerKey, group=None):
+        n_levels = plan.info()["n_levels"]
+        self.levels = [plan.export_level(l) for l in range(n_levels + 1)]
+        self.luts = plan.export_luts()
+        self.sk = sk
+        self.group = group
+        self.big = sk.params.big_size
+
+    def alloc_pool(self, slots):
+        return np.zeros((slots, self.big), dtype=np.uint64)
+
+    def load_inputs(self, pool, inputs, n_inputs):
+        pool[:n_inputs] = np.asarray(inputs, dtype=np.uint64).reshape(n_inputs, self.big)
+
+    def run_level_slice(self, pool, level, lo, hi):
+        lv = self.levels[level]
+        jobs = list(range(lo, hi))
+        staged = lincomb(pool, lv, jobs)
+        ids = sorted(set(int(lv["lut"][j]) for j in jobs))
+        luts = np.stack([self.luts[i] for i in ids])
+        idx = np.array([ids.index(int(lv["lut"][j])) for j in jobs], dtype=np.uint32)
+        pool[lv["base"] + lo: lv["base"] + hi] = self.sk.apply_lookup_table_batch(staged, luts, idx)
+
+    def all_gather(self, pool, base, per_rank, rank, world):
+        import torch
+        import torch.distributed as dist
+        region = torch.from_numpy(pool[base: base + per_rank * world].view(np.int64))
+        own = region[rank * per_rank: (rank + 1) * per_rank].clone()
+        dist.all_gather_into_tensor(region, own, group=self.group)
+
+    def gather_outputs(self, pool, n_outputs):
+        lv = self.levels[-1]
+        return lincomb(pool, lv, list(range(lv["jobs"])))
+
+
+def run_with_oracle(plan, inputs, sk, rank=0, world=1, group=None):
+    from fhestr.distributed import ShardedPlanRunner
+    return ShardedPlanRunner(plan, rank, world, OracleBackend(plan, sk, group)).run(inputs)

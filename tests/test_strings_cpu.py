@@ -1,0 +1,130 @@
+"""Host logic of the FheString plans without a GPU: the C++ planner builds offline plans, the CPU
+oracle executes their exported levels, results are compared with Python string semantics.  Also the
+world_size-2 gloo test of the sharded executor's protocol (fhestr/distributed.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import ROOT, keyset, to_fhestr_params
+from plan_oracle import run_with_oracle
+
+
+def _plan(op, a_cap, b_cap=0, clear=None, world=1):
+    import fhestr
+    return fhestr.Plan.string_op(None, op, a_cap, b_cap, clear, world, params=to_fhestr_params(O.TOY_K1))
+
+
+def _enc(ks, s, cap):
+    import fhestr
+    return ks.ck.encrypt_many(fhestr.string_to_blocks(to_fhestr_params(ks.params), s, cap))
+
+
+def _run(ks, op, s, pat, pat_cap=4):
+    if isinstance(pat, tuple):  # ("clear", bytes)
+        plan = _plan(op + "_clear", 8, 0, pat[1])
+        inputs = _enc(ks, s, 8)
+    elif pat is None:
+        plan = _plan(op, 8)
+        inputs = _enc(ks, s, 8)
+    else:
+        plan = _plan(op, 8, pat_cap)
+        inputs = np.concatenate([_enc(ks, s, 8), _enc(ks, pat, pat_cap)])
+    return ks.ck.decrypt_many(run_with_oracle(plan, inputs, ks.sk))
+
+
+CASES = [(b"hello wd", b"hell"), (b"hello wd", b"o wd"), (b"hello", b"lo"), (b"hello", b""), (b"", b""),
+         (b"", b"a"), (b"aaa", b"aa"), (b"ab", b"abc"), (b"abab", b"bab")]
+
+
+@pytest.mark.parametrize("s,pat", CASES)
+def test_pattern_ops_offline_plan_vs_python(toy_k1, s, pat):
+    for op, want in (("starts_with", s.startswith(pat)), ("ends_with", s.endswith(pat)), ("contains", pat in s),
+                     ("eq", s == pat), ("ne", s != pat)):
+        assert _run(toy_k1, op, s, pat)[0] == int(want), (op, "encrypted")
+        assert _run(toy_k1, op, s, ("clear", pat))[0] == int(want), (op, "clear")
+    want = s.find(pat)
+    for p in (pat, ("clear", pat)):
+        out = _run(toy_k1, "find", s, p)
+        assert out[0] == int(want >= 0)
+        if want >= 0:
+            assert sum(int(d) * 4**i for i, d in enumerate(out[1:])) == want
+
+
+@pytest.mark.parametrize("s", [b"Hello Wd", b"az AZ@[`", b""])
+def test_case_ops_offline_plan_vs_python(toy_k1, s):
+    import fhestr
+    P = to_fhestr_params(O.TOY_K1)
+    assert fhestr.blocks_to_string(P, _run(toy_k1, "to_upper", s, None)) == s.upper()
+    assert fhestr.blocks_to_string(P, _run(toy_k1, "to_lower", s, None)) == s.lower()
+
+
+def test_plan_shapes_match_survey_counts():
+    # eq enc-enc 256 chars = 1024 + 69 + 5 + 1 PBS, depth 4; enc-clear = 551
+    info = _plan("eq", 256, 256).info()
+    assert (info["n_pbs"], info["n_levels"], info["n_inputs"], info["n_outputs"]) == (1099, 4, 2048, 1)
+    info = _plan("eq_clear", 256, 0, b"x" * 200).info()
+    assert (info["n_pbs"], info["n_levels"]) == (551, 4)
+    lv = [_plan("eq", 256, 256).level_info(l)["jobs"] for l in range(4)]
+    assert lv == [1024, 69, 5, 1]
+
+
+def test_degree_overflow_is_a_build_error():
+    import fhestr
+    plan = fhestr.Plan(None, params=to_fhestr_params(O.TOY_K1))
+    a, b = plan.input(3), plan.input(3)
+    ident = plan.lut(lambda x: x)
+    with pytest.raises(fhestr.FheError):
+        plan.pbs(plan.lin([(a, 4), (b, 4)]), ident)   # 3*4 + 3*4 = 24 > 15
+
+
+def test_offline_plan_refuses_to_run():
+    import fhestr
+    plan = _plan("eq", 4, 4)
+    with pytest.raises(fhestr.FheError):
+        plan.run(np.zeros((plan.info()["n_inputs"], O.TOY_K1.big_size), dtype=np.uint64))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _gloo_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (ROOT, os.path.join(ROOT, "fhe-string-bounty_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ks = keyset(O.TOY_K1)
+        plan = _plan("contains", 8, 4, world=world)
+        inputs = np.concatenate([_enc(ks, b"abcabd", 8), _enc(ks, b"abd", 4)])  # deterministic per seed
+        out = run_with_oracle(plan, inputs, ks.sk, rank, world)
+        ret[rank] = int(ks.ck.decrypt_many(out)[0])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_runner_world2_gloo(toy_k1):
+    """N>1 path on CPU: two ranks each compute half of every level, all-gather, agree on the result
+    and agree with the single-rank run."""
+    import torch.multiprocessing as mp
+    world = 2
+    single = _run(toy_k1, "contains", b"abcabd", b"abd")[0]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert dict(ret) == {0: single, 1: single} and single == 1
