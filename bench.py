@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="LWEs per step per GPU")
     ap.add_argument("--log2-points", type=int, default=0, help="blind-rotate variant (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strings", action="store_true", help="skip the FheString ms/op section")
     return ap.parse_args()
 
 
@@ -63,6 +64,41 @@ def cpu_baseline(P, bsk, ksk, cts, lut_tables, lut_sel):
             "sample": f"the same {cts.shape[0]}-LWE batch, KS+PBS per LWE, {cores} host threads over LWEs "
                       f"(oracle/tfhe_oracle.c, gcc -O3; reference publishes 16.6 ms/PBS/core on Xeon 8375C)",
             "seconds": dt}, out
+
+
+def bench_strings(fhestr, eng, ck, P, rank, world, local_rank, reps=3):
+    """ms/op of FheString::eq (256 vs 256 chars, both encrypted) and ::contains (16-char encrypted
+    pattern in a 256-char haystack); every level's KS+PBS batch is split over the ranks."""
+    import torch
+    from fhestr.distributed import GpuBackend, ShardedPlanRunner
+    rng = np.random.default_rng(0x5EED0003)
+    hay = bytes(rng.integers(0x61, 0x7B, size=256, dtype=np.uint8))
+    off = int(rng.integers(0, 240))
+    pat = hay[off: off + 16]
+    enc = lambda s, cap: ck.encrypt(fhestr.string_to_blocks(P, s, cap))
+    cases = {
+        "eq_256_enc_enc": ("eq", 256, 256, np.concatenate([enc(hay, 256), enc(hay, 256)]), 1),
+        "contains_16_in_256_enc_enc": ("contains", 256, 16, np.concatenate([enc(hay, 256), enc(pat, 16)]), 1),
+    }
+    out = {}
+    dev = torch.device("cuda", local_rank)
+    for name, (op, a_cap, b_cap, inputs, want) in cases.items():
+        plan = fhestr.Plan.string_op(eng, op, a_cap, b_cap, world=world)
+        runner = ShardedPlanRunner(plan, rank, world, GpuBackend(plan, dev))
+        res = runner.run(inputs)   # warm-up + correctness
+        ok = int(ck.decrypt(res)[0]) == want
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            runner.run(inputs)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        info = plan.info()
+        out[name] = {"ms_per_op": ms, "n_pbs": info["n_pbs"], "levels": info["n_levels"], "correct": bool(ok),
+                     "pbs_per_s": info["n_pbs"] / (ms * 1e-3)}
+        plan.close()
+    eng.set_stream(None)
+    return out
 
 
 def main():
@@ -143,6 +179,12 @@ def main():
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
         verified = bool(v.item())
 
+    # ---- FheString ms/op (BASELINE.json configs 3 and 4): level batches sharded over the ranks,
+    #      one RCCL all-gather per level; single GPU = same code with world 1 ----
+    string_ops = None
+    if not args.no_strings:
+        string_ops = bench_strings(fhestr, eng, ck, P, rank, world, local_rank)
+
     if rank == 0:
         total_pbs = B * world * args.steps
         value = total_pbs / elapsed
@@ -168,6 +210,7 @@ def main():
             "whole_pbs_hbm_model": {"bytes_per_pbs": pbs_bytes,
                                     "frac_of_peak": value * pbs_bytes / (world * HBM_PEAK_GBS * 1e9)},
             "verified_decrypt": verified,
+            "string_ops": string_ops,
         }
         if not args.no_cpu_baseline and world == 1:
             try:

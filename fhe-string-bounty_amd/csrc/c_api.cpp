@@ -200,7 +200,14 @@ int fhe_plan_create_offline(const fhe_params_t* params, fhe_plan** out) {
 int fhe_engine_set_stream(fhe_engine* eng, void* hip_stream) {
     API_BEGIN
     CHECK_PTR(eng);
-    return eng->impl->set_stream((hipStream_t)hip_stream);
+    return eng->impl->set_stream((hipStream_t)hip_stream, false);
+    API_END
+}
+
+int fhe_engine_reset_stream(fhe_engine* eng) {
+    API_BEGIN
+    CHECK_PTR(eng);
+    return eng->impl->set_stream(nullptr, true);
     API_END
 }
 

@@ -50,7 +50,7 @@ struct Engine {
     int load_keys(const uint64_t* bsk_std, const uint64_t* ksk);
     uint64_t fill_accumulator(const uint64_t* table, std::vector<uint64_t>& acc) const { return fhe::fill_accumulator(p, table, acc); }
     int lut_upload_dedup(const std::vector<uint64_t>& acc, uint32_t* id);   // same contents -> same id
-    int set_stream(hipStream_t s);   // launch on a caller-owned stream (e.g. the framework's current stream)
+    int set_stream(hipStream_t s, bool use_own);   // launch on a caller-owned stream (e.g. the framework's current stream)
     int lut_upload(const uint64_t* acc, uint32_t* id);
     int lut_download(uint32_t id, uint64_t* acc);
     int ensure_batch(uint32_t count);

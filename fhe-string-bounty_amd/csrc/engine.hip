@@ -119,10 +119,10 @@ Engine::~Engine() {
     if (own_stream) (void)hipStreamDestroy(own_stream);
 }
 
-int Engine::set_stream(hipStream_t s) {
+int Engine::set_stream(hipStream_t s, bool use_own) {
     if (use()) return 1;
     HIP_TRY(hipStreamSynchronize(stream));
-    stream = s ? s : own_stream;
+    stream = use_own ? own_stream : s;   // s == nullptr is HIP's default (null) stream
     return 0;
 }
 

@@ -100,7 +100,7 @@ EXPORTS = [
     "fhe_plan_output", "fhe_plan_finalize", "fhe_plan_info", "fhe_plan_level_info", "fhe_plan_export_level",
     "fhe_plan_run", "fhe_plan_run_level_slice_dev", "fhe_plan_gather_outputs_dev", "fhe_str_plan_create",
     "fhe_str_to_upper", "fhe_str_to_lower", "fhe_plan_create_offline", "fhe_str_plan_create_offline",
-    "fhe_plan_lut_count", "fhe_plan_export_lut", "fhe_engine_set_stream",
+    "fhe_plan_lut_count", "fhe_plan_export_lut", "fhe_engine_set_stream", "fhe_engine_reset_stream",
 ] + [f"fhe_str_{n}{s}" for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find")
      for s in ("", "_clear")]
 
@@ -156,6 +156,7 @@ def lib() -> C.CDLL:
     sig("fhe_plan_lut_count", vp, C.POINTER(u32))
     sig("fhe_plan_export_lut", vp, u32, vp)
     sig("fhe_engine_set_stream", vp, vp)
+    sig("fhe_engine_reset_stream", vp)
     sig("fhe_plan_input", vp, C.c_uint64, C.POINTER(u32))
     sig("fhe_plan_lut", vp, vp, C.POINTER(u32))
     sig("fhe_plan_lin", vp, vp, vp, u32, C.c_int64, C.POINTER(u32))
@@ -228,8 +229,12 @@ class Engine:
         _check(lib().fhe_engine_synchronize(self._h))
 
     def set_stream(self, hip_stream: int | None):
-        """Launch on a caller-owned stream (e.g. torch.cuda.current_stream().cuda_stream)."""
-        _check(lib().fhe_engine_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+        """Launch on a caller-owned stream handle (e.g. torch.cuda.current_stream().cuda_stream; 0 is
+        HIP's default stream).  None switches back to the engine's own stream."""
+        if hip_stream is None:
+            _check(lib().fhe_engine_reset_stream(self._h))
+        else:
+            _check(lib().fhe_engine_set_stream(self._h, C.c_void_p(hip_stream)))
 
     def load_keys(self, bsk_std, ksk):
         p = self.params

@@ -56,10 +56,11 @@ int fhe_engine_params(const fhe_engine *eng, fhe_params_t *out);
 int fhe_engine_load_keys(fhe_engine *eng, const uint64_t *bsk_std, const uint64_t *ksk);
 /* The engine's HIP stream (hipStream_t) so callers can order their own work against it. */
 void *fhe_engine_stream(fhe_engine *eng);
-/* Launch on a caller-owned hipStream_t instead (NULL = back to the engine's own stream), e.g. the
- * framework stream RCCL collectives are enqueued on, so no host synchronisation is needed between
- * a level's kernels and its all-gather. */
+/* Launch on a caller-owned hipStream_t instead (NULL = HIP's default stream), e.g. the framework
+ * stream RCCL collectives are enqueued on, so no host synchronisation is needed between a level's
+ * kernels and its all-gather.  fhe_engine_reset_stream goes back to the engine's own stream. */
 int fhe_engine_set_stream(fhe_engine *eng, void *hip_stream);
+int fhe_engine_reset_stream(fhe_engine *eng);
 int fhe_engine_synchronize(fhe_engine *eng);
 /* Choose the blind-rotation variant: points per thread = 2^log2_points (0 = automatic). */
 int fhe_engine_set_variant(fhe_engine *eng, int log2_points);

@@ -135,3 +135,38 @@ def test_p22_contains_find_16_in_256(p22):
     absent = b"0123456789ABCDEF"
     assert _dec(p22, ops.contains(eh, _enc(p22, absent, 16)))[0] == 0
     assert _dec(p22, ops.contains(eh, _enc(p22, pat, 16)))[0] == 1
+
+
+def test_sharded_runner_gpu_backend_single_rank(toy_k1):
+    """The multi-GPU executor's product backend on one GPU (world 1) incl. a forced all-gather
+    through a 1-rank RCCL group: same result as fhe_plan_run."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import fhestr
+    from fhestr.distributed import GpuBackend, ShardedPlanRunner
+    eng = gpu_engine(toy_k1)
+    plan = fhestr.Plan.string_op(eng, "find", 8, 4)
+    inputs = np.concatenate([_enc(toy_k1, b"xxabdabd", 8), _enc(toy_k1, b"abd", 4)])
+    want = _dec(toy_k1, plan.run(inputs))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")   # make sure the CUDA/HIP context exists before the RCCL group
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        backend = GpuBackend(plan, torch.device("cuda", 0))
+        runner = ShardedPlanRunner(plan, 0, 1, backend)
+        got = _dec(toy_k1, runner.run(inputs))
+        assert np.array_equal(got, want) and got[0] == 1 and got[1] + 4 * got[2] == 2
+        # exercise the collective itself on a level region
+        pool = backend.alloc_pool(plan.info()["pool_slots"])
+        lv = plan.level_info(0)
+        backend.all_gather(pool, lv["base"], lv["per_rank"], 0, 1)
+        torch.cuda.synchronize()
+    finally:
+        eng.set_stream(None)
+        if created:
+            dist.destroy_process_group()
