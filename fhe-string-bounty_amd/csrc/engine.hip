@@ -35,7 +35,9 @@ int fail(const std::string& msg) {
 // ---- blind-rotation variant registry ----------------------------------------------------------
 struct BrVariant {
     int logN, k1, L, logR;
+    bool wide;          // true: every thread carries all k+1 polynomials (blind_rotate_wide_kernel)
     int threads;
+    int convert_threads;
     size_t lds_bytes;
     size_t convert_lds;
     const void* rotate_fn;
@@ -46,12 +48,24 @@ template <int LOGN, int LOGR, int K1, int L>
 BrVariant make_variant() {
     using CFG = BrCfg<LOGN, LOGR, K1, L>;
     BrVariant v;
-    v.logN = LOGN; v.k1 = K1; v.L = L; v.logR = LOGR;
+    v.logN = LOGN; v.k1 = K1; v.L = L; v.logR = LOGR; v.wide = false;
     v.threads = CFG::THREADS;
-    v.lds_bytes = CFG::LDS_BYTES;
-    v.convert_lds = (size_t)K1 * 2 * CFG::P * 8;
+    v.convert_threads = CFG::THREADS;
+    v.lds_bytes = CFG::LDS_FIXED;   // + 4*n for the modulus-switched mask
+    v.convert_lds = (size_t)K1 * CFG::GROUP_SLOTS * 8;
     v.rotate_fn = reinterpret_cast<const void*>(&blind_rotate_kernel<LOGN, LOGR, K1, L>);
     v.convert_fn = reinterpret_cast<const void*>(&bsk_convert_kernel<LOGN, LOGR, K1, L>);
+    return v;
+}
+
+template <int LOGN, int LOGR, int K1, int L>
+BrVariant make_wide_variant() {
+    using CFG = BrWideCfg<LOGN, LOGR, K1, L>;
+    BrVariant v = make_variant<LOGN, LOGR, K1, L>();   // same Fourier key layout + conversion kernel
+    v.wide = true;
+    v.threads = CFG::THREADS;
+    v.lds_bytes = CFG::LDS_FIXED;
+    v.rotate_fn = reinterpret_cast<const void*>(&blind_rotate_wide_kernel<LOGN, LOGR, K1, L>);
     return v;
 }
 
@@ -59,22 +73,27 @@ static const std::vector<BrVariant>& variants() {
     static const std::vector<BrVariant> v = {
         // PARAM_MESSAGE_2_CARRY_2_KS_PBS: N=2048, k=1, l=1  (first entry of a shape = default)
         make_variant<11, 2, 2, 1>(), make_variant<11, 3, 2, 1>(), make_variant<11, 4, 2, 1>(),
+        make_wide_variant<11, 2, 2, 1>(), make_wide_variant<11, 3, 2, 1>(),
         // N=1024, k=2, l=1 family (PARAM_MESSAGE_2_CARRY_1_KS_PBS ...)
-        make_variant<10, 3, 3, 1>(), make_variant<10, 2, 3, 1>(),
+        make_variant<10, 3, 3, 1>(), make_variant<10, 2, 3, 1>(), make_wide_variant<10, 2, 3, 1>(),
         // PARAM_MESSAGE_1_CARRY_1_KS_PBS: N=512, k=3, l=1
         make_variant<9, 2, 4, 1>(),
         // toy shapes used by the fast tests
         make_variant<8, 2, 2, 2>(), make_variant<7, 2, 3, 1>(),
+        make_wide_variant<8, 2, 2, 2>(), make_wide_variant<7, 2, 3, 1>(),
     };
     return v;
 }
 
-static const BrVariant* find_variant(const fhe_params_t& p, int logR) {
+// selector: 0 = default; otherwise log2(points per thread) + 16 if the "wide" layout is wanted
+static const BrVariant* find_variant(const fhe_params_t& p, int selector) {
     int logN = 0;
     while ((1u << logN) < p.N) logN++;
+    const int logR = selector & 15;
+    const bool wide = (selector & 16) != 0;
     for (const auto& v : variants())
         if (v.logN == logN && v.k1 == (int)p.k + 1 && v.L == (int)p.pbs_level &&
-            (logR == 0 || v.logR == logR))
+            (selector == 0 || (v.logR == logR && v.wide == wide)))
             return &v;
     return nullptr;
 }
@@ -172,12 +191,12 @@ int Engine::load_keys(const uint64_t* bsk_std, const uint64_t* ksk) {
     void* args[] = {(void*)&d_std, (void*)&d_fbsk, (void*)&n_polys};
     HIP_TRY(hipFuncSetAttribute(variant->convert_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)variant->convert_lds));
-    HIP_TRY(hipLaunchKernel(variant->convert_fn, dim3((n_polys + k1 - 1) / k1), dim3(variant->threads),
+    HIP_TRY(hipLaunchKernel(variant->convert_fn, dim3((n_polys + k1 - 1) / k1), dim3(variant->convert_threads),
                             args, variant->convert_lds, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipFree(d_std));
     HIP_TRY(hipFuncSetAttribute(variant->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)variant->lds_bytes));
+                                (int)(variant->lds_bytes + (size_t)p.n * 4)));
     return 0;
 }
 
@@ -259,7 +278,7 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
     BlindRotateArgs a{d_sm, d_lut_idx, d_luts, d_fbsk, d_big, p.n, p.pbs_base_log, count};
     void* args[] = {(void*)&a};
     HIP_TRY(hipLaunchKernel(variant->rotate_fn, dim3(count), dim3(variant->threads), args,
-                            variant->lds_bytes, stream));
+                            variant->lds_bytes + (size_t)p.n * 4, stream));
     return 0;
 }
 

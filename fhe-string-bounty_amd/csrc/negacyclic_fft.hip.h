@@ -18,6 +18,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Device arithmetic may fuse multiply-add (v_fma_f64); host code of the library stays unfused so that
+// client-side key generation is bit-reproducible against the oracle.
+#pragma clang fp contract(fast)
+
 namespace fhe {
 
 struct cplx {
@@ -138,19 +142,69 @@ struct FftPlan {
     __host__ __device__ static constexpr int log_S(int s) { return LOGP - (s < FULL ? s : FULL) * LOGR; }
 };
 
-// LDS slot swizzle hook (8-byte slots).  Identity for now.
-__device__ __forceinline__ int lds_slot(int a) { return a; }
+// ---- LDS slot swizzle (8-byte slots) ----------------------------------------------------------
+// ds_read_b64 serves a wave as two 32-lane groups (32 distinct slots mod 32 = conflict free),
+// ds_write_b64 as four 16-lane groups (16 distinct slots mod 16).  The in-place exchange touches
+// each layout with both, and later passes stride by powers of two, so the plain index conflicts
+// 2-8 ways.  Fix: a GF(2)-linear map of the low five slot bits, slot' = (a & ~31) | XOR_j a_j*col[j];
+// the column constants come from scripts/find_swizzle.py (exhaustive check of every pass layout).
+// Linear => slot'(base ^ c) = slot'(base) ^ slot'(c): the per-register part folds to a constant.
+template <int LP, int LR>
+struct SwzCols {
+    static constexpr bool identity = true;
+    static constexpr int col[16] = {1, 2, 4, 8, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+};
+#define FHE_SWZ(LP, LR, ...)                                     \
+    template <>                                                  \
+    struct SwzCols<LP, LR> {                                     \
+        static constexpr bool identity = false;                  \
+        static constexpr int col[16] = {__VA_ARGS__};            \
+    };
+FHE_SWZ(10, 2, 5, 26, 3, 8, 9, 23, 16, 8, 10, 0, 0, 0, 0, 0, 0, 0)
+FHE_SWZ(10, 3, 9, 4, 17, 2, 3, 24, 5, 16, 3, 12, 0, 0, 0, 0, 0, 0)
+FHE_SWZ(10, 4, 6, 9, 24, 3, 2, 1, 14, 4, 21, 0, 0, 0, 0, 0, 0, 0)
+FHE_SWZ(9, 3, 5, 2, 4, 26, 8, 4, 29, 16, 1, 0, 0, 0, 0, 0, 0, 0)
+FHE_SWZ(9, 2, 5, 24, 2, 6, 17, 11, 16, 2, 2, 0, 0, 0, 0, 0, 0, 0)
+FHE_SWZ(8, 2, 10, 1, 25, 4, 12, 3, 16, 8, 0, 0, 0, 0, 0, 0, 0, 0)
+#undef FHE_SWZ
+
+template <class PL>
+__device__ __forceinline__ int lds_slot(int a) {
+    using SW = SwzCols<PL::LOGP, PL::LOGR>;
+    if (SW::identity) return a;
+    int bank = 0;
+#pragma unroll
+    for (int j = 0; j < PL::LOGP; j++) bank ^= (-((a >> j) & 1)) & SW::col[j];
+    return (a & ~31) | bank;
+}
 
 // Element address (in points) handled by thread tau, group gi, butterfly input m in pass s.
+// Full-radix passes: tau = Q*S_{s+1} + t'.  Trailing (grouped) pass: pair index = tau*groups + gi,
+// so that the exchange feeding it stays inside S_{s+1}-thread neighbourhoods (wave-local).
 template <class PL>
 __device__ __forceinline__ int pass_addr(int s, int tau, int gi, int m) {
     const int lr = PL::log_radix(s);
     const int lS = PL::log_S(s);
     const int lS1 = lS - lr;                 // log2 S_{s+1}
-    const int pi = tau + PL::T * gi;         // (Q, t') pair index
+    const int lg = PL::LOGR - lr;            // log2 groups
+    const int pi = (tau << lg) + gi;         // (Q, t') pair index
     const int Q = pi >> lS1;
     const int tp = pi & ((1 << lS1) - 1);
     return (Q << lS) + (m << lS1) + tp;
+}
+
+// Synchronise the threads that exchange data between pass s and pass s+1.  Those are aligned
+// neighbourhoods of S_{s+1} threads; when that fits one wavefront, in-order LDS execution of a
+// single wave makes a workgroup barrier unnecessary (only the compiler must not reorder).
+template <class PL>
+__device__ __forceinline__ void exchange_sync(int s_next) {
+    if ((1 << PL::log_S(s_next)) <= 64 && PL::T >= 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
 }
 
 // Per-thread constants of one polynomial group.
@@ -189,15 +243,17 @@ __device__ __forceinline__ void fft_forward(cplx* x, const FftConsts<PL>& c, dou
         const int rr = 1 << lr;
         const int groups = R / rr;
         if (s > 0) {
-            __syncthreads();
+            exchange_sync<PL>(s);
 #pragma unroll
-            for (int gi = 0; gi < groups; gi++)
+            for (int gi = 0; gi < groups; gi++) {
+                const int base = lds_slot<PL>(pass_addr<PL>(s, tau, gi, 0));
 #pragma unroll
                 for (int m = 0; m < rr; m++) {
-                    const int a = lds_slot(pass_addr<PL>(s, tau, gi, m));
+                    const int a = base ^ lds_slot<PL>(pass_addr<PL>(s, 0, 0, m));
                     x[gi * rr + m].re = re[a];
                     x[gi * rr + m].im = im[a];
                 }
+            }
         }
         if (lr == PL::LOGR) {
             small_dft<R, false>(x);
@@ -211,13 +267,15 @@ __device__ __forceinline__ void fft_forward(cplx* x, const FftConsts<PL>& c, dou
         }
         if (s + 1 < PL::NP) {
 #pragma unroll
-            for (int gi = 0; gi < groups; gi++)
+            for (int gi = 0; gi < groups; gi++) {
+                const int base = lds_slot<PL>(pass_addr<PL>(s, tau, gi, 0));
 #pragma unroll
                 for (int m = 0; m < rr; m++) {
-                    const int a = lds_slot(pass_addr<PL>(s, tau, gi, m));
+                    const int a = base ^ lds_slot<PL>(pass_addr<PL>(s, 0, 0, m));
                     re[a] = x[gi * rr + m].re;
                     im[a] = x[gi * rr + m].im;
                 }
+            }
         }
     }
 }
@@ -233,15 +291,17 @@ __device__ __forceinline__ void fft_inverse(cplx* x, const FftConsts<PL>& c, dou
         const int rr = 1 << lr;
         const int groups = R / rr;
         if (s + 1 < PL::NP) {
-            __syncthreads();
+            exchange_sync<PL>(s + 1);
 #pragma unroll
-            for (int gi = 0; gi < groups; gi++)
+            for (int gi = 0; gi < groups; gi++) {
+                const int base = lds_slot<PL>(pass_addr<PL>(s, tau, gi, 0));
 #pragma unroll
                 for (int m = 0; m < rr; m++) {
-                    const int a = lds_slot(pass_addr<PL>(s, tau, gi, m));
+                    const int a = base ^ lds_slot<PL>(pass_addr<PL>(s, 0, 0, m));
                     x[gi * rr + m].re = re[a];
                     x[gi * rr + m].im = im[a];
                 }
+            }
         }
         if (s < PL::NTW) {
 #pragma unroll
@@ -255,13 +315,129 @@ __device__ __forceinline__ void fft_inverse(cplx* x, const FftConsts<PL>& c, dou
         }
         if (s > 0) {
 #pragma unroll
-            for (int gi = 0; gi < groups; gi++)
+            for (int gi = 0; gi < groups; gi++) {
+                const int base = lds_slot<PL>(pass_addr<PL>(s, tau, gi, 0));
 #pragma unroll
                 for (int m = 0; m < rr; m++) {
-                    const int a = lds_slot(pass_addr<PL>(s, tau, gi, m));
+                    const int a = base ^ lds_slot<PL>(pass_addr<PL>(s, 0, 0, m));
                     re[a] = x[gi * rr + m].re;
                     im[a] = x[gi * rr + m].im;
                 }
+            }
+        }
+    }
+}
+
+// ---- NP polynomials per thread ------------------------------------------------------------------
+// Same transforms, but every thread carries the R points of NPOLY independent polynomials (same
+// indices): the pass loop is outermost so one synchronisation covers all of them and the compiler
+// can overlap one polynomial's LDS round trip with another one's butterflies.  `re0` is the first
+// polynomial's real plane; planes of polynomial p start at re0 + p*poly_stride, imaginary plane at
+// +im_off.
+template <class PL, int NPOLY>
+__device__ __forceinline__ void fft_forward_multi(cplx (*x)[PL::R], const FftConsts<PL>& c, double* re0,
+                                                  int poly_stride, int im_off, int tau) {
+    constexpr int R = PL::R;
+#pragma unroll
+    for (int s = 0; s < PL::NP; s++) {
+        const int lr = PL::log_radix(s);
+        const int rr = 1 << lr;
+        const int groups = R / rr;
+        if (s > 0) {
+            exchange_sync<PL>(s);
+#pragma unroll
+            for (int gi = 0; gi < groups; gi++) {
+                const int base = lds_slot<PL>(pass_addr<PL>(s, tau, gi, 0));
+#pragma unroll
+                for (int p = 0; p < NPOLY; p++)
+#pragma unroll
+                    for (int m = 0; m < rr; m++) {
+                        const int a = base ^ lds_slot<PL>(pass_addr<PL>(s, 0, 0, m));
+                        x[p][gi * rr + m].re = re0[p * poly_stride + a];
+                        x[p][gi * rr + m].im = re0[p * poly_stride + im_off + a];
+                    }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NPOLY; p++) {
+            if (lr == PL::LOGR) {
+                small_dft<R, false>(x[p]);
+            } else {
+#pragma unroll
+                for (int gi = 0; gi < groups; gi++) small_dft<(1 << PL::LOGLAST), false>(x[p] + gi * rr);
+            }
+            if (s < PL::NTW) {
+#pragma unroll
+                for (int q = 1; q < R; q++) x[p][q] = cmul(x[p][q], c.tw[s][q]);
+            }
+        }
+        if (s + 1 < PL::NP) {
+#pragma unroll
+            for (int gi = 0; gi < groups; gi++) {
+                const int base = lds_slot<PL>(pass_addr<PL>(s, tau, gi, 0));
+#pragma unroll
+                for (int p = 0; p < NPOLY; p++)
+#pragma unroll
+                    for (int m = 0; m < rr; m++) {
+                        const int a = base ^ lds_slot<PL>(pass_addr<PL>(s, 0, 0, m));
+                        re0[p * poly_stride + a] = x[p][gi * rr + m].re;
+                        re0[p * poly_stride + im_off + a] = x[p][gi * rr + m].im;
+                    }
+            }
+        }
+    }
+}
+
+template <class PL, int NPOLY>
+__device__ __forceinline__ void fft_inverse_multi(cplx (*x)[PL::R], const FftConsts<PL>& c, double* re0,
+                                                  int poly_stride, int im_off, int tau) {
+    constexpr int R = PL::R;
+#pragma unroll
+    for (int s = PL::NP - 1; s >= 0; s--) {
+        const int lr = PL::log_radix(s);
+        const int rr = 1 << lr;
+        const int groups = R / rr;
+        if (s + 1 < PL::NP) {
+            exchange_sync<PL>(s + 1);
+#pragma unroll
+            for (int gi = 0; gi < groups; gi++) {
+                const int base = lds_slot<PL>(pass_addr<PL>(s, tau, gi, 0));
+#pragma unroll
+                for (int p = 0; p < NPOLY; p++)
+#pragma unroll
+                    for (int m = 0; m < rr; m++) {
+                        const int a = base ^ lds_slot<PL>(pass_addr<PL>(s, 0, 0, m));
+                        x[p][gi * rr + m].re = re0[p * poly_stride + a];
+                        x[p][gi * rr + m].im = re0[p * poly_stride + im_off + a];
+                    }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NPOLY; p++) {
+            if (s < PL::NTW) {
+#pragma unroll
+                for (int q = 1; q < R; q++) x[p][q] = cmul_conj(x[p][q], c.tw[s][q]);
+            }
+            if (lr == PL::LOGR) {
+                small_dft<R, true>(x[p]);
+            } else {
+#pragma unroll
+                for (int gi = 0; gi < groups; gi++) small_dft<(1 << PL::LOGLAST), true>(x[p] + gi * rr);
+            }
+        }
+        if (s > 0) {
+#pragma unroll
+            for (int gi = 0; gi < groups; gi++) {
+                const int base = lds_slot<PL>(pass_addr<PL>(s, tau, gi, 0));
+#pragma unroll
+                for (int p = 0; p < NPOLY; p++)
+#pragma unroll
+                    for (int m = 0; m < rr; m++) {
+                        const int a = base ^ lds_slot<PL>(pass_addr<PL>(s, 0, 0, m));
+                        re0[p * poly_stride + a] = x[p][gi * rr + m].re;
+                        re0[p * poly_stride + im_off + a] = x[p][gi * rr + m].im;
+                    }
+            }
         }
     }
 }

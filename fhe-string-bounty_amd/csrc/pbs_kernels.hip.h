@@ -67,8 +67,14 @@ struct BrCfg {
     static constexpr int T = PL::T;
     static constexpr int THREADS = K1 * T;
     // LDS: accumulator copy (rotation gather source) + FFT exchange planes + spectrum broadcast
-    static constexpr size_t LDS_BYTES = (size_t)K1 * N * 8 /*acc*/ + (size_t)K1 * 2 * P * 8 /*x*/ +
-                                        (size_t)K1 * 2 * P * 8 /*F*/;
+    // the imaginary plane sits PLANE = P + 2 slots after the real one: an offset that is neither
+    // <= 255 slots nor a multiple of 64 slots, so hipcc cannot fuse a re/im pair into one
+    // ds_read2st64_b64 / ds_write2st64_b64 (half the LDS bandwidth of two plain 8-byte accesses)
+    static constexpr int PLANE = P + 2;
+    static constexpr int GROUP_SLOTS = 2 * P + 4;
+    static constexpr size_t LDS_FIXED = (size_t)K1 * N * 8 /*acc*/ + (size_t)K1 * GROUP_SLOTS * 8 /*x*/ +
+                                        (size_t)K1 * GROUP_SLOTS * 8 /*F*/;
+    static size_t lds_bytes(uint32_t n) { return LDS_FIXED + (size_t)n * 4; }   // + modswitched mask
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -80,8 +86,8 @@ bsk_convert_kernel(const uint64_t* __restrict__ bsk_std, double* __restrict__ fb
     constexpr int N = CFG::N, P = CFG::P, R = CFG::R, T = CFG::T;
     extern __shared__ __align__(16) unsigned char smem[];
     const int g = threadIdx.x / T, tau = threadIdx.x % T;
-    double* xre = reinterpret_cast<double*>(smem) + (size_t)g * 2 * P;
-    double* xim = xre + P;
+    double* xre = reinterpret_cast<double*>(smem) + (size_t)g * CFG::GROUP_SLOTS;
+    double* xim = xre + CFG::PLANE;
     const uint32_t poly = blockIdx.x * K1 + g;   // K1 polynomials per workgroup
     const bool active = poly < n_polys;
     FftConsts<PL> fc;
@@ -94,8 +100,9 @@ bsk_convert_kernel(const uint64_t* __restrict__ bsk_std, double* __restrict__ fb
         uint64_t b = active ? bsk_std[(size_t)poly * N + j + P] : 0;
         // forward_as_torus: signed value * 2^-64 (fft/mod.rs:197-218)
         cplx z;
-        z.re = i64_to_f64(a) * 5.421010862427522e-20;
-        z.im = i64_to_f64(b) * 5.421010862427522e-20;
+        // the inverse transform's 1/(N/2) (fft/mod.rs:285-304) is folded in here: linear, exact (power of two)
+        z.re = i64_to_f64(a) * (5.421010862427522e-20 / P);
+        z.im = i64_to_f64(b) * (5.421010862427522e-20 / P);
         double sn, cs;
         sincospi((double)j / (double)N, &sn, &cs);  // twisty e^{i pi j / N}
         cplx w; w.re = cs; w.im = sn;
@@ -112,6 +119,14 @@ bsk_convert_kernel(const uint64_t* __restrict__ bsk_std, double* __restrict__ fb
 // ------------------------------------------------------------------------------------------------
 // One workgroup = one LWE sample; K1 groups of T threads, group g owns GLWE polynomial g of the
 // accumulator (2R coefficients per thread, in VGPRs for the whole kernel).
+//
+// LDS regions (disjoint, so that no barrier is needed just to recycle memory):
+//   lds_acc [K1][N] u64      copy of the accumulator, gather source of the monomial rotation
+//   lds_x   [K1][2][P] f64   FFT exchange planes (swizzled slots)
+//   lds_f   [K1][2][P] f64   spectrum broadcast between the polynomial groups
+//   lds_d   [n] u32          modulus-switched mask elements (0xFFFFFFFF marks a_i == 0)
+// Barriers per CMUX step: forward exchange 0->1, spectrum publish, inverse exchange 1->0, accumulator
+// publish; every other exchange is wave-local.
 template <int LOGN, int LOGR, int K1, int L>
 __global__ void __launch_bounds__((BrCfg<LOGN, LOGR, K1, L>::THREADS))
 blind_rotate_kernel(BlindRotateArgs args) {
@@ -120,8 +135,9 @@ blind_rotate_kernel(BlindRotateArgs args) {
     constexpr int N = CFG::N, P = CFG::P, R = CFG::R, T = CFG::T;
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t* lds_acc = reinterpret_cast<uint64_t*>(smem);                       // [K1][N]
-    double* lds_x = reinterpret_cast<double*>(smem + (size_t)K1 * N * 8);        // [K1][2][P]
-    double* lds_f = lds_x + (size_t)K1 * 2 * P;                                  // [K1][2][P]
+    double* lds_x = reinterpret_cast<double*>(smem + (size_t)K1 * N * 8);        // [K1][GROUP_SLOTS]
+    double* lds_f = lds_x + (size_t)K1 * CFG::GROUP_SLOTS;                       // [K1][GROUP_SLOTS]
+    uint32_t* lds_d = reinterpret_cast<uint32_t*>(lds_f + (size_t)K1 * CFG::GROUP_SLOTS);   // [n]
 
     const int g = threadIdx.x / T, tau = threadIdx.x % T;
     const uint32_t sample = blockIdx.x;
@@ -129,20 +145,25 @@ blind_rotate_kernel(BlindRotateArgs args) {
     const uint64_t* lwe = args.lwe_small + (size_t)sample * (n + 1);
     const uint64_t* lut = args.luts + (size_t)(args.lut_idx ? args.lut_idx[sample] : 0) * K1 * N;
     uint64_t* my_acc = lds_acc + (size_t)g * N;
-    double* xre = lds_x + (size_t)g * 2 * P;
-    double* xim = xre + P;
+    double* xre = lds_x + (size_t)g * CFG::GROUP_SLOTS;
+    double* xim = xre + CFG::PLANE;
     const uint32_t bL = args.base_log * L;
 
-    // per-thread constants: inter-pass twiddles, twisties (forward) and conj(twisty)/P (backward)
+    // modulus switch of the whole mask once (fft_impl/common.rs:26-43); a_i == 0 is skipped (:281)
+    for (uint32_t i = threadIdx.x; i < n; i += CFG::THREADS) {
+        const uint64_t a = lwe[i];
+        lds_d[i] = a == 0 ? 0xFFFFFFFFu : modulus_switch(a, LOGN);
+    }
+
+    // per-thread constants: inter-pass twiddles and twisties (1/P is folded into the Fourier key)
     FftConsts<PL> fc;
     fft_init_consts<PL>(fc, tau);
-    cplx twist[R], untwist[R];
+    cplx twist[R];
 #pragma unroll
     for (int m = 0; m < R; m++) {
         double sn, cs;
         sincospi((double)(tau + T * m) / (double)N, &sn, &cs);
         twist[m].re = cs; twist[m].im = sn;
-        untwist[m].re = cs * (1.0 / P); untwist[m].im = sn * (1.0 / P);  // used through cmul_conj
     }
 
     // acc <- LUT * X^{-ms(body)}   (bootstrap.rs:254-271, polynomial_algorithms.rs:331-353)
@@ -174,12 +195,25 @@ blind_rotate_kernel(BlindRotateArgs args) {
     const double2* fbsk = reinterpret_cast<const double2*>(args.fbsk);
     constexpr size_t GGSW_ELEMS = (size_t)L * K1 * K1 * P;   // complex elements per GGSW
 
+    uint32_t d_next = lds_d[0];
     for (uint32_t i = 0; i < n; i++) {
-        const uint64_t a_i = lwe[i];
-        if (a_i == 0) continue;                                  // bootstrap.rs:281 (block-uniform)
-        const uint32_t d = modulus_switch(a_i, LOGN);
+        const uint32_t d = d_next;
+        d_next = lds_d[i + 1 < n ? i + 1 : i];                  // prefetch (LDS broadcast read)
+        if (d == 0xFFFFFFFFu) continue;                          // block-uniform
         const uint32_t rem = d & (N - 1);
         const bool odd = (d >> LOGN) & 1;
+
+        // Fourier GGSW rows of the last decomposition level handled first (ggsw.rs:524): issue the
+        // global loads now, they land while the forward FFT runs (L2 / Infinity-Cache resident key)
+        const double2* bk0 = fbsk + (size_t)i * GGSW_ELEMS;
+        double2 bpre[K1][R];
+        {
+            const double2* bk = bk0 + (size_t)(L - 1) * K1 * K1 * P;
+#pragma unroll
+            for (int row = 0; row < K1; row++)
+#pragma unroll
+                for (int rho = 0; rho < R; rho++) bpre[row][rho] = bk[((size_t)row * K1 + g) * P + rho * T + tau];
+        }
 
         // ct1 = acc * X^d - acc  (polynomial_algorithms.rs:463-489), then decomposition state
         uint32_t st_lo[R], st_hi[R];
@@ -211,11 +245,11 @@ blind_rotate_kernel(BlindRotateArgs args) {
                 x[m] = cmul(z, twist[m]);                        // fft/mod.rs:220-239
             }
             fft_forward<PL>(x, fc, xre, xim, tau);
-            // publish this row's spectrum
+            // publish this row's spectrum for the other polynomial groups
             if (it > 0) __syncthreads();                         // previous level's readers done
             {
-                double* fre = lds_f + (size_t)g * 2 * P;
-                double* fim = fre + P;
+                double* fre = lds_f + (size_t)g * CFG::GROUP_SLOTS;
+                double* fim = fre + CFG::PLANE;
 #pragma unroll
                 for (int rho = 0; rho < R; rho++) {
                     fre[rho * T + tau] = x[rho].re;
@@ -224,18 +258,21 @@ blind_rotate_kernel(BlindRotateArgs args) {
             }
             __syncthreads();
             // outf[col = g] (+)= sum_row FBSK[i][lvl][row][g] * F[row]   (ggsw.rs:616-697)
-            const double2* bk = fbsk + (size_t)i * GGSW_ELEMS + (size_t)lvl_idx * K1 * K1 * P;
+            const double2* bk = bk0 + (size_t)lvl_idx * K1 * K1 * P;
 #pragma unroll
             for (int row = 0; row < K1; row++) {
-                const double* fre = lds_f + (size_t)row * 2 * P;
-                const double* fim = fre + P;
-                const double2* b = bk + ((size_t)row * K1 + g) * P;
+                const double* fre = lds_f + (size_t)row * CFG::GROUP_SLOTS;
+                const double* fim = fre + CFG::PLANE;
 #pragma unroll
                 for (int rho = 0; rho < R; rho++) {
-                    const double2 bv = b[rho * T + tau];
+                    const double2 bv = it == 0 ? bpre[row][rho] : bk[((size_t)row * K1 + g) * P + rho * T + tau];
                     cplx f;
-                    f.re = fre[rho * T + tau];
-                    f.im = fim[rho * T + tau];
+                    if (row == g) {
+                        f = x[rho];                              // own spectrum is still in registers
+                    } else {
+                        f.re = fre[rho * T + tau];
+                        f.im = fim[rho * T + tau];
+                    }
                     if (it == 0 && row == 0) {
                         outf[rho].re = bv.x * f.re - bv.y * f.im;
                         outf[rho].im = bv.x * f.im + bv.y * f.re;
@@ -247,12 +284,13 @@ blind_rotate_kernel(BlindRotateArgs args) {
             }
         }
 
-        // back to the standard domain and accumulate (fft/mod.rs:285-304, 539-557)
+        // back to the standard domain and accumulate (fft/mod.rs:285-304, 539-557); the 1/(N/2)
+        // normalisation lives in the Fourier key (bsk_convert_kernel)
         fft_inverse<PL>(outf, fc, xre, xim, tau);
         // every gather of this step's my_acc happened several barriers ago: safe to overwrite
 #pragma unroll
         for (int m = 0; m < R; m++) {
-            cplx t = cmul_conj(outf[m], untwist[m]);
+            cplx t = cmul_conj(outf[m], twist[m]);
             acc_lo[m] += from_torus(t.re);
             acc_hi[m] += from_torus(t.im);
             my_acc[tau + T * m] = acc_lo[m];
@@ -277,6 +315,193 @@ blind_rotate_kernel(BlindRotateArgs args) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Variant "wide": one workgroup = one LWE, T = N/2/R threads, every thread carries the same R
+// spectrum slots of ALL k+1 polynomials.  The Fourier-domain multiply-accumulate against the GGSW
+// is then thread-local (no spectrum broadcast through LDS, no barrier for it), each thread has
+// k+1 independent FFT streams to overlap LDS round trips with butterflies, and the smaller
+// footprint (accumulator copy + exchange planes) lets two LWEs share a CU for batches >= 512.
+// Barriers per CMUX step: forward exchange 0->1, inverse exchange 1->0, accumulator publish.
+template <int LOGN, int LOGR, int K1, int L>
+struct BrWideCfg {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int P = N / 2;
+    using PL = FftPlan<LOGN - 1, LOGR>;
+    static constexpr int R = PL::R;
+    static constexpr int T = PL::T;
+    static constexpr int THREADS = T;
+    static constexpr int PLANE = P + 2;
+    static constexpr int GROUP_SLOTS = 2 * P + 4;
+    static constexpr size_t LDS_FIXED = (size_t)K1 * N * 8 /*acc*/ + (size_t)K1 * GROUP_SLOTS * 8 /*x*/;
+    // keep the whole Fourier GGSW of a step in VGPRs only when it is small
+    static constexpr bool PREFETCH_ALL = K1 * K1 * R * 4 <= 64;
+};
+
+template <int LOGN, int LOGR, int K1, int L>
+__global__ void __launch_bounds__((BrWideCfg<LOGN, LOGR, K1, L>::THREADS))
+blind_rotate_wide_kernel(BlindRotateArgs args) {
+    using CFG = BrWideCfg<LOGN, LOGR, K1, L>;
+    using PL = typename CFG::PL;
+    constexpr int N = CFG::N, P = CFG::P, R = CFG::R, T = CFG::T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t* lds_acc = reinterpret_cast<uint64_t*>(smem);                       // [K1][N]
+    double* lds_x = reinterpret_cast<double*>(smem + (size_t)K1 * N * 8);        // [K1][GROUP_SLOTS]
+    uint32_t* lds_d = reinterpret_cast<uint32_t*>(lds_x + (size_t)K1 * CFG::GROUP_SLOTS);   // [n]
+
+    const int tau = threadIdx.x;
+    const uint32_t sample = blockIdx.x;
+    const uint32_t n = args.n;
+    const uint64_t* lwe = args.lwe_small + (size_t)sample * (n + 1);
+    const uint64_t* lut = args.luts + (size_t)(args.lut_idx ? args.lut_idx[sample] : 0) * K1 * N;
+    const uint32_t bL = args.base_log * L;
+
+    for (uint32_t i = threadIdx.x; i < n; i += CFG::THREADS) {
+        const uint64_t a = lwe[i];
+        lds_d[i] = a == 0 ? 0xFFFFFFFFu : modulus_switch(a, LOGN);
+    }
+
+    FftConsts<PL> fc;
+    fft_init_consts<PL>(fc, tau);
+    cplx twist[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        double sn, cs;
+        sincospi((double)(tau + T * m) / (double)N, &sn, &cs);
+        twist[m].re = cs; twist[m].im = sn;
+    }
+
+    uint64_t acc_lo[K1][R], acc_hi[K1][R];
+    {
+        const uint32_t d = modulus_switch(lwe[n], LOGN);
+        const uint32_t rem = d & (N - 1);
+        const bool odd = (d >> LOGN) & 1;
+#pragma unroll
+        for (int p = 0; p < K1; p++)
+#pragma unroll
+            for (int m = 0; m < R; m++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t j = tau + T * m + h * P;
+                    const uint32_t src = (j + rem) & (N - 1);
+                    const bool neg = ((j + rem) >= (uint32_t)N) != odd;
+                    uint64_t v = lut[(size_t)p * N + src];
+                    v = neg ? (0 - v) : v;
+                    if (h == 0) acc_lo[p][m] = v; else acc_hi[p][m] = v;
+                    lds_acc[(size_t)p * N + j] = v;
+                }
+    }
+    __syncthreads();
+
+    const double2* fbsk = reinterpret_cast<const double2*>(args.fbsk);
+    constexpr size_t GGSW_ELEMS = (size_t)L * K1 * K1 * P;
+
+    uint32_t d_next = lds_d[0];
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t d = d_next;
+        d_next = lds_d[i + 1 < n ? i + 1 : i];
+        if (d == 0xFFFFFFFFu) continue;
+        const uint32_t rem = d & (N - 1);
+        const bool odd = (d >> LOGN) & 1;
+        const double2* bk0 = fbsk + (size_t)i * GGSW_ELEMS;
+
+        double2 bpre[CFG::PREFETCH_ALL ? K1 : 1][CFG::PREFETCH_ALL ? K1 : 1][R];
+        if (CFG::PREFETCH_ALL) {
+            const double2* bk = bk0 + (size_t)(L - 1) * K1 * K1 * P;
+#pragma unroll
+            for (int row = 0; row < K1; row++)
+#pragma unroll
+                for (int col = 0; col < K1; col++)
+#pragma unroll
+                    for (int rho = 0; rho < R; rho++)
+                        bpre[row][col][rho] = bk[((size_t)row * K1 + col) * P + rho * T + tau];
+        }
+
+        uint32_t st_lo[K1][R], st_hi[K1][R];
+#pragma unroll
+        for (int p = 0; p < K1; p++)
+#pragma unroll
+            for (int m = 0; m < R; m++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t j = tau + T * m + h * P;
+                    const uint32_t src = (j - rem) & (N - 1);
+                    const bool neg = (j < rem) != odd;
+                    uint64_t v = lds_acc[(size_t)p * N + src];
+                    v = neg ? (0 - v) : v;
+                    const uint64_t own = h == 0 ? acc_lo[p][m] : acc_hi[p][m];
+                    const uint32_t st = decomp_init_state(v - own, bL);
+                    if (h == 0) st_lo[p][m] = st; else st_hi[p][m] = st;
+                }
+
+        cplx outf[K1][R];
+#pragma unroll
+        for (int it = 0; it < L; it++) {
+            const int lvl_idx = L - 1 - it;
+            cplx x[K1][R];
+#pragma unroll
+            for (int p = 0; p < K1; p++)
+#pragma unroll
+                for (int m = 0; m < R; m++) {
+                    cplx z;
+                    z.re = (double)decomp_next_digit(st_lo[p][m], args.base_log);
+                    z.im = (double)decomp_next_digit(st_hi[p][m], args.base_log);
+                    x[p][m] = cmul(z, twist[m]);
+                }
+            fft_forward_multi<PL, K1>(x, fc, lds_x, CFG::GROUP_SLOTS, CFG::PLANE, tau);
+            const double2* bk = bk0 + (size_t)lvl_idx * K1 * K1 * P;
+#pragma unroll
+            for (int row = 0; row < K1; row++)
+#pragma unroll
+                for (int col = 0; col < K1; col++)
+#pragma unroll
+                    for (int rho = 0; rho < R; rho++) {
+                        const double2 bv = (CFG::PREFETCH_ALL && it == 0)
+                                               ? bpre[CFG::PREFETCH_ALL ? row : 0][CFG::PREFETCH_ALL ? col : 0][rho]
+                                               : bk[((size_t)row * K1 + col) * P + rho * T + tau];
+                        const cplx f = x[row][rho];
+                        if (it == 0 && row == 0) {
+                            outf[col][rho].re = bv.x * f.re - bv.y * f.im;
+                            outf[col][rho].im = bv.x * f.im + bv.y * f.re;
+                        } else {
+                            outf[col][rho].re = fma(bv.x, f.re, fma(-bv.y, f.im, outf[col][rho].re));
+                            outf[col][rho].im = fma(bv.x, f.im, fma(bv.y, f.re, outf[col][rho].im));
+                        }
+                    }
+            if (it + 1 < L) __syncthreads();   // next level's pass-0 writes vs this level's last reads
+        }
+
+        fft_inverse_multi<PL, K1>(outf, fc, lds_x, CFG::GROUP_SLOTS, CFG::PLANE, tau);
+#pragma unroll
+        for (int p = 0; p < K1; p++)
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                cplx t = cmul_conj(outf[p][m], twist[m]);
+                acc_lo[p][m] += from_torus(t.re);
+                acc_hi[p][m] += from_torus(t.im);
+                lds_acc[(size_t)p * N + tau + T * m] = acc_lo[p][m];
+                lds_acc[(size_t)p * N + tau + T * m + P] = acc_hi[p][m];
+            }
+        __syncthreads();
+    }
+
+    uint64_t* out = args.lwe_out + (size_t)sample * ((size_t)(K1 - 1) * N + 1);
+#pragma unroll
+    for (int p = 0; p < K1; p++)
+#pragma unroll
+        for (int m = 0; m < R; m++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t j = tau + T * m + h * P;
+                const uint64_t v = h == 0 ? acc_lo[p][m] : acc_hi[p][m];
+                if (p == K1 - 1) {
+                    if (j == 0) out[(size_t)(K1 - 1) * N] = v;
+                } else {
+                    if (j == 0) out[(size_t)p * N] = v;
+                    else out[(size_t)p * N + (N - j)] = 0 - v;
+                }
+            }
 }
 
 }  // namespace fhe

@@ -164,3 +164,32 @@ def test_p22_batch_256_decrypts(p22):
     got = eng.apply_lookup_table(cts, np.array([ids[s] for s in sel], dtype=np.uint32))
     dec = p22.ck.decrypt_many(got)
     assert np.array_equal(dec, tables[sel, msgs])
+
+
+@pytest.mark.parametrize("selector", [2, 3, 4, 18, 19], ids=lambda s: f"variant{s}")
+def test_p22_every_blind_rotate_variant(p22, selector):
+    """All instantiated blind-rotation variants (points per thread 4/8/16, split and wide layouts)
+    give decrypt-exact results and bit-exact zero-mask PBS on PARAM_MESSAGE_2_CARRY_2."""
+    eng = gpu_engine(p22, selector)
+    lut, _ = p22.sk.generate_lookup_table(lambda x: (x * 7 + 3) % 16)
+    lut_id = eng.upload_lut(lut)
+    msgs = np.arange(32) % 16
+    cts = p22.ck.encrypt_many(msgs, O.Rng(123, selector))
+    got = eng.apply_lookup_table(cts, np.full(32, lut_id, dtype=np.uint32))
+    assert np.array_equal(p22.ck.decrypt_many(got), (msgs * 7 + 3) % 16)
+    small = np.zeros((5, p22.params.small_size), dtype=np.uint64)
+    small[:, -1] = np.array([0, 2**64 - 1, 2**63, 12345678901234567, 2**62 + 5], dtype=np.uint64)
+    want = np.stack([p22.sk.pbs(s, lut) for s in small])
+    assert np.array_equal(eng.pbs(small, np.full(5, lut_id, dtype=np.uint32)), want)
+
+
+@pytest.mark.parametrize("params,selector", [(O.TOY_K1, 18), (O.TOY_K2, 18)], ids=["toy_k1_wide", "toy_k2_wide"])
+def test_toy_wide_variants(params, selector):
+    ks = keyset(params)
+    eng = gpu_engine(ks, selector)
+    M = params.msg_mod * params.carry_mod
+    lut, _ = ks.sk.generate_lookup_table(lambda x: (M - 1 - x))
+    lut_id = eng.upload_lut(lut)
+    cts = ks.ck.encrypt_many(list(range(M)) * 2, O.Rng(5, 5))
+    got = eng.apply_lookup_table(cts, np.full(2 * M, lut_id, dtype=np.uint32))
+    assert np.array_equal(ks.ck.decrypt_many(got), np.array([M - 1 - m for m in range(M)] * 2))
