@@ -28,7 +28,9 @@ struct Engine {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // scratch triple (unused slots of the ring below)
     std::vector<hipEvent_t> ring;   // 3 events per recorded ks_pbs call
     size_t ring_used = 0;           // calls recorded since the last reset
-    const BrVariant* variant = nullptr;
+    const BrVariant* variant = nullptr;       // layout used up to one LWE per CU
+    const BrVariant* variant_large = nullptr; // same Fourier-key layout, used for larger batches (may equal variant)
+    int cu_count = 256;
 
     // resident keys / tables
     uint64_t* d_ksk = nullptr;

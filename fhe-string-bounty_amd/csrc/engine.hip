@@ -120,6 +120,14 @@ int Engine::create(const fhe_params_t& p, int device, Engine** out) {
     e->p = p;
     e->device = device;
     e->variant = v;
+    e->variant_large = v;
+    if (env_logr == 0) {   // automatic: "wide" twin (same points per thread => same key layout) for big batches
+        const BrVariant* w = find_variant(p, v->logR | 16);
+        if (w) e->variant_large = w;
+    }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    e->cu_count = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
     for (auto& ev : e->ev) HIP_TRY(hipEventCreate(&ev));
@@ -167,10 +175,20 @@ static int ensure(void** ptr, size_t* cap, size_t bytes) {
 int Engine::set_variant(int logR) {
     const BrVariant* v = find_variant(p, logR);
     if (!v) return fail("no such blind-rotation variant for these parameters");
-    if (v == variant) return 0;
     if (d_fbsk && v->logR != variant->logR)
         return fail("variant must be chosen before fhe_engine_load_keys (Fourier key layout depends on it)");
     variant = v;
+    variant_large = v;
+    if (logR == 0) {
+        const BrVariant* w = find_variant(p, v->logR | 16);
+        if (w) variant_large = w;
+    }
+    if (d_fbsk) {
+        HIP_TRY(hipFuncSetAttribute(variant->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(variant->lds_bytes + (size_t)p.n * 4)));
+        HIP_TRY(hipFuncSetAttribute(variant_large->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(variant_large->lds_bytes + (size_t)p.n * 4)));
+    }
     return 0;
 }
 
@@ -197,6 +215,8 @@ int Engine::load_keys(const uint64_t* bsk_std, const uint64_t* ksk) {
     HIP_TRY(hipFree(d_std));
     HIP_TRY(hipFuncSetAttribute(variant->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(variant->lds_bytes + (size_t)p.n * 4)));
+    HIP_TRY(hipFuncSetAttribute(variant_large->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(variant_large->lds_bytes + (size_t)p.n * 4)));
     return 0;
 }
 
@@ -277,8 +297,11 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
     if (n_luts == 0) return fail("no lookup table uploaded");
     BlindRotateArgs a{d_sm, d_lut_idx, d_luts, d_fbsk, d_big, p.n, p.pbs_base_log, count};
     void* args[] = {(void*)&a};
-    HIP_TRY(hipLaunchKernel(variant->rotate_fn, dim3(count), dim3(variant->threads), args,
-                            variant->lds_bytes + (size_t)p.n * 4, stream));
+    // one LWE per CU or fewer: spread it over more threads; above that: the compact layout that
+    // lets two LWEs share a CU
+    const BrVariant* v = count > (uint32_t)cu_count ? variant_large : variant;
+    HIP_TRY(hipLaunchKernel(v->rotate_fn, dim3(count), dim3(v->threads), args,
+                            v->lds_bytes + (size_t)p.n * 4, stream));
     return 0;
 }
 

@@ -52,6 +52,14 @@ __device__ __forceinline__ int32_t decomp_next_digit(uint32_t& state, uint32_t b
     state += carry;
     return (int32_t)(res - (carry << base_log));
 }
+// Single-level fast path (L == 1): the state IS the only digit's residue, so
+// digit = res - (res > B/2 ? B : 0)  -- the same value iter.rs:120-127 yields when state >> b == 0
+// (carry = bit b-1 of ((res-1) & res) = [res > B/2]).
+__device__ __forceinline__ int32_t decomp_single_digit(uint64_t x, uint32_t b) {
+    const uint32_t t = (uint32_t)(x >> 32) >> (31 - b);          // b+1 top bits (b <= 31)
+    const uint32_t res = ((t + 1u) >> 1) & ((1u << b) - 1u);
+    return (int32_t)res - (int32_t)(res > (1u << (b - 1)) ? (1u << b) : 0u);
+}
 // fft_impl/common.rs:26-43 (offset 0, lut_count_log 0): result in [0, 2N]
 __device__ __forceinline__ uint32_t modulus_switch(uint64_t x, int logN) {
     uint64_t o = x >> (64 - logN - 2);
@@ -227,7 +235,7 @@ blind_rotate_kernel(BlindRotateArgs args) {
                 uint64_t v = my_acc[src];
                 v = neg ? (0 - v) : v;
                 const uint64_t own = h == 0 ? acc_lo[m] : acc_hi[m];
-                const uint32_t st = decomp_init_state(v - own, bL);
+                const uint32_t st = L == 1 ? (uint32_t)decomp_single_digit(v - own, bL) : decomp_init_state(v - own, bL);
                 if (h == 0) st_lo[m] = st; else st_hi[m] = st;
             }
         }
@@ -240,8 +248,8 @@ blind_rotate_kernel(BlindRotateArgs args) {
 #pragma unroll
             for (int m = 0; m < R; m++) {
                 cplx z;
-                z.re = (double)decomp_next_digit(st_lo[m], args.base_log);
-                z.im = (double)decomp_next_digit(st_hi[m], args.base_log);
+                z.re = (double)(L == 1 ? (int32_t)st_lo[m] : decomp_next_digit(st_lo[m], args.base_log));
+                z.im = (double)(L == 1 ? (int32_t)st_hi[m] : decomp_next_digit(st_hi[m], args.base_log));
                 x[m] = cmul(z, twist[m]);                        // fft/mod.rs:220-239
             }
             fft_forward<PL>(x, fc, xre, xim, tau);
@@ -431,7 +439,7 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
                     uint64_t v = lds_acc[(size_t)p * N + src];
                     v = neg ? (0 - v) : v;
                     const uint64_t own = h == 0 ? acc_lo[p][m] : acc_hi[p][m];
-                    const uint32_t st = decomp_init_state(v - own, bL);
+                    const uint32_t st = L == 1 ? (uint32_t)decomp_single_digit(v - own, bL) : decomp_init_state(v - own, bL);
                     if (h == 0) st_lo[p][m] = st; else st_hi[p][m] = st;
                 }
 
@@ -445,8 +453,8 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
 #pragma unroll
                 for (int m = 0; m < R; m++) {
                     cplx z;
-                    z.re = (double)decomp_next_digit(st_lo[p][m], args.base_log);
-                    z.im = (double)decomp_next_digit(st_hi[p][m], args.base_log);
+                    z.re = (double)(L == 1 ? (int32_t)st_lo[p][m] : decomp_next_digit(st_lo[p][m], args.base_log));
+                    z.im = (double)(L == 1 ? (int32_t)st_hi[p][m] : decomp_next_digit(st_hi[p][m], args.base_log));
                     x[p][m] = cmul(z, twist[m]);
                 }
             fft_forward_multi<PL, K1>(x, fc, lds_x, CFG::GROUP_SLOTS, CFG::PLANE, tau);
