@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from dataclasses import dataclass
 
 import numpy as np
@@ -113,6 +114,15 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise FheError(f"{LIB_PATH} is missing: run `make -C fhe-string-bounty_amd` "
                        "(or __graft_entry__.build()); there is no CPU fallback")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64: two HIP runtimes in
+    # one process do not see the same device (the second one finds no GPU) and cannot share streams.
+    # Importing torch first makes its copy the process-wide one; libfhestr.so (NEEDED libamdhip64.so.7)
+    # then binds to it, so torch streams / tensors and the engine live in a single runtime.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
     PP = C.POINTER(_Params)
