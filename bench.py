@@ -194,6 +194,14 @@ def main():
         br_avg_ms = br_ms / max(calls, 1)
         achieved = br_bytes * B / (br_avg_ms * 1e-3) / 1e9
         pbs_bytes = P.bsk_len * 8 + P.ksk_len * 8 + 2 * P.big_size * 8 + P.glwe_len * 8  # 109,559,824
+        # HBM-side bytes per launch from the committed rocprofv3 PMC passes (same kernel, same batch)
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["blind_rotate_kernel"]
+            if tj["batch"] == B and args.log2_points == 0:
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+        except Exception:
+            pass
         rec = {
             "metric": "PBS/sec (whole node)", "value": value, "unit": "PBS/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -203,7 +211,7 @@ def main():
                                    "PARAM_MESSAGE_2_CARRY_2_KS_PBS, 16 random LUTs, 1xMI355X per rank",
                        "batch_per_gpu": B, "params": P.name, "parallelism": f"replicated keys x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "blind_rotate_kernel", "avg_launch_ms": br_avg_ms,
                          "algorithmic_bytes_per_lwe": br_bytes, "lwes_per_launch": B},
             "kernel_ms": {"keyswitch": ks_ms / max(calls, 1), "blind_rotate": br_avg_ms, "launches": calls},
