@@ -430,6 +430,27 @@ STR_BINARY(ends_with)
 STR_BINARY(contains)
 STR_BINARY(find)
 
+int fhe_str_replace(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, const uint64_t* from_to,
+                    uint32_t pat_cap, uint64_t* out) {
+    if (!from_to) return fail("null pointer: from_to");
+    return str_op(eng, "replace", a, a_cap, from_to, 2 * pat_cap, nullptr, 0, out);
+}
+int fhe_str_replace_clear(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, const uint8_t* from,
+                          const uint8_t* to, uint32_t pat_len, uint64_t* out) {
+    if (pat_len && (!from || !to)) return fail("null pointer: from / to");
+    std::vector<uint8_t> both(from, from + pat_len);
+    both.insert(both.end(), to, to + pat_len);
+    return str_op(eng, "replace_clear", a, a_cap, nullptr, 0, both.data(), 2 * pat_len, out);
+}
+int fhe_str_trim_start(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, uint64_t* out) {
+    return str_op(eng, "trim_start", a, a_cap, nullptr, 0, nullptr, 0, out);
+}
+int fhe_str_trim_end(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, uint64_t* out) {
+    return str_op(eng, "trim_end", a, a_cap, nullptr, 0, nullptr, 0, out);
+}
+int fhe_str_strip(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, uint64_t* out) {
+    return str_op(eng, "strip", a, a_cap, nullptr, 0, nullptr, 0, out);
+}
 int fhe_str_to_upper(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, uint64_t* out) {
     return str_op(eng, "to_upper", a, a_cap, nullptr, 0, nullptr, 0, out);
 }

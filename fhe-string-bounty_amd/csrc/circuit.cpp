@@ -36,21 +36,23 @@ void Circuit::flatten(uint32_t id, int64_t mult, std::map<uint32_t, int64_t>& ac
 uint32_t Circuit::lin(const std::vector<Term>& terms, int64_t cst, int64_t degree_override) {
     std::map<uint32_t, int64_t> acc;
     int64_t c = cst;
+    // degree bound from the operands as given (an operand LIN may carry a tighter, caller-asserted
+    // bound than its flattened leaves would suggest)
+    int64_t maxv = cst > 0 ? cst : 0;
     for (const Term& t : terms) {
         if (t.node >= nodes_.size()) { error_ = "lin: bad node id"; return 0; }
+        if (t.coeff > 0) maxv += (int64_t)t.coeff * (int64_t)nodes_[t.node].degree;
         flatten(t.node, t.coeff, acc, c);
     }
     Node n;
     n.kind = Node::LIN;
     n.cst = c;
     uint32_t lvl = 0;
-    int64_t maxv = c > 0 ? c : 0;
     for (auto& kv : acc) {
         if (kv.second == 0) continue;
         if (kv.second > INT32_MAX || kv.second < INT32_MIN) { error_ = "lin: coefficient overflow"; return 0; }
         n.terms.push_back({kv.first, (int32_t)kv.second});
         lvl = std::max(lvl, nodes_[kv.first].level);
-        if (kv.second > 0) maxv += kv.second * (int64_t)nodes_[kv.first].degree;
     }
     n.level = lvl;
     n.degree = degree_override >= 0 ? (uint64_t)degree_override : (uint64_t)maxv;

@@ -368,6 +368,143 @@ public:
             }
         }
     }
+
+    // ---- whitespace trimming ----
+    // wz[i] = [s[i] is ASCII whitespace (9..13, 32)] (+ [s[i] == 0] when null_too): 3 PBS per char
+    std::vector<uint32_t> whitespace_bits(const Str& s, bool null_too) {
+        const uint32_t hi_lut = c.lut_fn([](uint64_t x) { return (uint64_t)(x == 0 ? 1 : (x == 2 ? 2 : 0)); });
+        const uint32_t lo_lut = c.lut_fn([null_too](uint64_t x) {
+            const bool row0 = (x >= 9 && x <= 13) || (null_too && x == 0);
+            return (uint64_t)((row0 ? 1 : 0) | (x == 0 ? 2 : 0));
+        });
+        const uint32_t comb = c.lut_fn([](uint64_t x) {
+            const uint64_t a = x / 4, b = x % 4;
+            return (uint64_t)(((a == 1 && (b & 1)) || (a == 2 && (b & 2))) ? 1 : 0);
+        });
+        const uint32_t half = bpc / 2;
+        std::vector<uint32_t> out;
+        for (uint32_t i = 0; i < s.cap; i++) {
+            std::vector<Term> lo_terms, hi_terms;
+            for (uint32_t k = 0; k < half; k++) {
+                lo_terms.push_back({s.ch[i][k], (int32_t)(1u << (k * bits_per_block))});
+                hi_terms.push_back({s.ch[i][half + k], (int32_t)(1u << (k * bits_per_block))});
+            }
+            const uint32_t hc = c.pbs(c.lin(hi_terms), hi_lut), lc = c.pbs(c.lin(lo_terms), lo_lut);
+            out.push_back(c.pbs(c.lin({{hc, 4}, {lc, 1}}), comb));
+        }
+        return out;
+    }
+    // block * bit (bit in {0,1}) : LUT on bit + 2*block  (noise: 1 + 2*level(block))
+    uint32_t gate_block(uint32_t block, uint32_t bit, bool keep_if_set) {
+        const uint32_t m2 = 2 * M;
+        const uint32_t l = c.lut_fn([keep_if_set, m2](uint64_t x) {
+            return (uint64_t)((x < m2 && ((x & 1) != 0) == keep_if_set) ? x >> 1 : 0);
+        });
+        return c.pbs(c.lin({{bit, 1}, {block, 2}}), l);
+    }
+    uint32_t not_bit(uint32_t bit) { return c.lin({{bit, -1}}, 1, 1); }
+    // trim_end: zero every char from the last non-whitespace one onwards
+    Str trim_end(const Str& s) {
+        std::vector<uint32_t> wz = whitespace_bits(s, true), nw(s.cap);
+        for (uint32_t i = 0; i < s.cap; i++) nw[s.cap - 1 - i] = not_bit(wz[i]);   // reversed, 1 = real char
+        std::vector<uint32_t> keep_rev = prefix_or(nw);        // keep[i] = OR_{j >= i} nonws[j]
+        Str out;
+        out.cap = s.cap;
+        out.ch.resize(s.cap);
+        for (uint32_t i = 0; i < s.cap; i++)
+            for (uint32_t k = 0; k < bpc; k++) out.ch[i].push_back(gate_block(s.ch[i][k], keep_rev[s.cap - 1 - i], true));
+        return out;
+    }
+    // trim_start: shift left by the (encrypted) number of leading whitespace chars with a barrel
+    // shifter; stage t shifts by 2^t iff the first 2^t chars are all whitespace
+    Str trim_start(const Str& s) {
+        std::vector<uint32_t> ws = whitespace_bits(s, false), nws(s.cap);
+        for (uint32_t i = 0; i < s.cap; i++) nws[i] = not_bit(ws[i]);
+        std::vector<uint32_t> seen = prefix_or(nws);           // seen[i] = some non-ws char in [0, i]
+        std::vector<uint32_t> lead(s.cap);                     // lead[i] = chars 0..i all whitespace
+        for (uint32_t i = 0; i < s.cap; i++) lead[i] = not_bit(seen[i]);
+        Str cur = s;
+        int top = 0;
+        while ((1u << (top + 1)) <= s.cap) top++;
+        for (int t = top; t >= 0; t--) {
+            const uint32_t sh = 1u << t;
+            if (sh > s.cap) continue;
+            const uint32_t sel = lead[sh - 1];
+            Str nxt;
+            nxt.cap = s.cap;
+            nxt.ch.resize(s.cap);
+            std::vector<uint32_t> nlead(s.cap);
+            for (uint32_t i = 0; i < s.cap; i++) {
+                for (uint32_t k = 0; k < bpc; k++) {
+                    const uint32_t stay = gate_block(cur.ch[i][k], sel, false);
+                    if (i + sh < s.cap) nxt.ch[i].push_back(c.lin({{stay, 1}, {gate_block(cur.ch[i + sh][k], sel, true), 1}}, 0, M - 1));
+                    else nxt.ch[i].push_back(stay);
+                }
+                // the monotone indicator shifts with the string
+                const uint32_t stay = gate_block(lead[i], sel, false);
+                nlead[i] = i + sh < s.cap ? c.lin({{stay, 1}, {gate_block(lead[i + sh], sel, true), 1}}, 0, 1) : stay;
+            }
+            cur = nxt;
+            lead = nlead;
+        }
+        return cur;
+    }
+
+    // ---- replace (equal-length pattern and replacement) ----
+    // sel[o] = match[o] and no selected match in the m-1 offsets before it (leftmost, non-overlapping)
+    std::vector<uint32_t> select_non_overlapping(const std::vector<uint32_t>& match, uint32_t m, bool may_overlap) {
+        if (!may_overlap || m <= 1) return match;
+        std::vector<uint32_t> sel(match.size());
+        const uint32_t l = c.lut_fn([](uint64_t x) { return (uint64_t)(x == 1); });
+        for (size_t o = 0; o < match.size(); o++) {
+            std::vector<Term> terms{{match[o], 1}};
+            for (uint32_t j = 1; j < m && j <= o; j++) terms.push_back({sel[o - j], 2});
+            sel[o] = terms.size() == 1 ? match[o] : c.pbs(c.lin(terms, 0, 3), l);   // at most one earlier sel is set
+        }
+        return sel;
+    }
+    // to: clear bytes (to_clear) or encrypted chars (to_enc, cap == m)
+    Str replace_from_sel(const Str& s, const std::vector<uint32_t>& sel, uint32_t m, const uint8_t* to_clear, const Str* to_enc) {
+        Str out;
+        out.cap = s.cap;
+        out.ch.resize(s.cap);
+        std::map<std::pair<uint32_t, uint32_t>, uint32_t> prod;   // (offset, j*bpc+k) -> sel[o] * to[j].block k
+        for (uint32_t i = 0; i < s.cap; i++) {
+            std::vector<Term> cover_terms;
+            for (uint32_t j = 0; j < m && j <= i; j++)
+                if (i - j < sel.size()) cover_terms.push_back({sel[i - j], 1});
+            if (cover_terms.empty()) { out.ch[i] = s.ch[i]; continue; }
+            uint32_t cover = c.lin(cover_terms, 0, 1);
+            if (cover_terms.size() > 3) cover = c.pbs(cover, c.lut_fn([](uint64_t x) { return (uint64_t)(x != 0); }));
+            for (uint32_t k = 0; k < bpc; k++) {
+                std::vector<Term> terms{{gate_block(s.ch[i][k], cover, false), 1}};
+                for (uint32_t j = 0; j < m && j <= i; j++) {
+                    if (i - j >= sel.size()) continue;
+                    if (to_clear) {
+                        const uint32_t v = clear_block(to_clear[j], k);
+                        if (v) terms.push_back({sel[i - j], (int32_t)v});
+                    } else {
+                        terms.push_back({gate_block(to_enc->ch[j][k], sel[i - j], true), 1});
+                    }
+                }
+                uint32_t blk = c.lin(terms, 0, M - 1);   // at most one contribution is non-zero
+                int64_t weight = 0;
+                for (const Term& t : terms) weight += t.coeff;
+                if (weight > (int64_t)T - 1) blk = c.pbs(blk, c.lut_fn([this](uint64_t x) { return x % M; }));
+                out.ch[i].push_back(blk);
+            }
+        }
+        return out;
+    }
+    static bool has_border(const uint8_t* p, uint32_t m) {   // proper prefix == suffix => matches may overlap
+        for (uint32_t b = 1; b < m; b++)
+            if (std::memcmp(p, p + m - b, b) == 0) return true;
+        return false;
+    }
+    void emit(const Str& s) {
+        for (auto& blocks : s.ch)
+            for (uint32_t b : blocks) c.output(b);
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -382,7 +519,9 @@ int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t 
     if (is_clear && !clear && clear_len) return fail("null clear pattern");
     Str a = s.input_string(a_cap);
     Str b;
-    const bool unary = base == "to_upper" || base == "to_lower";
+    const bool unary = base == "to_upper" || base == "to_lower" || base == "trim_start" || base == "trim_end" ||
+                       base == "strip" || base == "trim";
+    const bool is_replace = base == "replace";
     if (!is_clear && !unary) {
         if (b_cap == 0) return fail("pattern capacity must be > 0");
         b = s.input_string(b_cap);
@@ -410,10 +549,42 @@ int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t 
         std::vector<uint32_t> outs;
         s.find_from_matches(match, n_digits, outs);
         for (uint32_t o : outs) c.output(o);
-    } else if (unary) {
+    } else if (base == "to_upper" || base == "to_lower") {
         std::vector<uint32_t> outs;
         s.change_case(a, base == "to_lower", outs);
         for (uint32_t o : outs) c.output(o);
+    } else if (base == "trim_end") {
+        s.emit(s.trim_end(a));
+    } else if (base == "trim_start") {
+        s.emit(s.trim_start(a));
+    } else if (base == "strip" || base == "trim") {
+        s.emit(s.trim_start(s.trim_end(a)));
+    } else if (is_replace) {
+        // replace_clear: clear = from || to (two halves of equal length m)
+        // replace:       b = encrypted from || to (capacity 2m, no padding inside either half)
+        if (is_clear) {
+            if (clear_len % 2) return fail("replace_clear expects `from` and `to` of equal length, concatenated");
+            const uint32_t m = clear_len / 2;
+            if (m == 0 || m > a_cap) { s.emit(a); }
+            else {
+                std::vector<uint32_t> match = s.window_matches_clear(a, clear, m, a_cap - m + 1);
+                std::vector<uint32_t> sel = s.select_non_overlapping(match, m, StrOps::has_border(clear, m));
+                s.emit(s.replace_from_sel(a, sel, m, clear + m, nullptr));
+            }
+        } else {
+            if (b_cap % 2) return fail("replace expects `from` and `to` of equal capacity, concatenated");
+            const uint32_t m = b_cap / 2;
+            if (m > a_cap) { s.emit(a); }
+            else {
+                Str from, to;
+                from.cap = to.cap = m;
+                from.ch.assign(b.ch.begin(), b.ch.begin() + m);
+                to.ch.assign(b.ch.begin() + m, b.ch.end());
+                std::vector<uint32_t> match = s.window_matches(a, from, a_cap - m + 1, false);
+                std::vector<uint32_t> sel = s.select_non_overlapping(match, m, true);
+                s.emit(s.replace_from_sel(a, sel, m, nullptr, &to));
+            }
+        }
     } else {
         return fail("unknown string op: " + op);
     }

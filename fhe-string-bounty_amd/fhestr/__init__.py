@@ -101,6 +101,7 @@ EXPORTS = [
     "fhe_plan_output", "fhe_plan_finalize", "fhe_plan_info", "fhe_plan_level_info", "fhe_plan_export_level",
     "fhe_plan_run", "fhe_plan_run_level_slice_dev", "fhe_plan_gather_outputs_dev", "fhe_str_plan_create",
     "fhe_str_to_upper", "fhe_str_to_lower", "fhe_plan_create_offline", "fhe_str_plan_create_offline",
+    "fhe_str_trim_start", "fhe_str_trim_end", "fhe_str_strip", "fhe_str_replace", "fhe_str_replace_clear",
     "fhe_plan_lut_count", "fhe_plan_export_lut", "fhe_engine_set_stream", "fhe_engine_reset_stream",
 ] + [f"fhe_str_{n}{s}" for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find")
      for s in ("", "_clear")]
@@ -183,6 +184,10 @@ def lib() -> C.CDLL:
     for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find"):
         sig(f"fhe_str_{n}", vp, vp, u32, vp, u32, vp)
         sig(f"fhe_str_{n}_clear", vp, vp, u32, vp, u32, vp)
+    for n in ("trim_start", "trim_end", "strip"):
+        sig(f"fhe_str_{n}", vp, vp, u32, vp)
+    sig("fhe_str_replace", vp, vp, u32, vp, u32, vp)
+    sig("fhe_str_replace_clear", vp, vp, u32, vp, vp, u32, vp)
     sig("fhe_str_to_upper", vp, vp, u32, vp)
     sig("fhe_str_to_lower", vp, vp, u32, vp)
     for name in ("fhe_params_ksk_len", "fhe_params_bsk_len"):
@@ -584,6 +589,29 @@ class FheStringOps:
         a, a_cap = self._cap(a)
         out = np.zeros_like(a)
         _check(getattr(lib(), f"fhe_str_{op}")(self.engine.handle, _ptr(a), a_cap, _ptr(out)))
+        return out
+
+    def trim_start(self, a): return self._unary("trim_start", a)
+    def trim_end(self, a): return self._unary("trim_end", a)
+    def strip(self, a): return self._unary("strip", a)
+
+    def replace(self, a, frm, to):
+        """Equal-length replace; frm/to both bytes (clear) or both encrypted (same capacity, unpadded)."""
+        a, a_cap = self._cap(a)
+        out = np.zeros_like(a)
+        if isinstance(frm, (bytes, bytearray)):
+            if len(frm) != len(to):
+                raise FheError("replace: `from` and `to` must have the same length")
+            fb = (C.c_uint8 * max(1, len(frm)))(*frm)
+            tb = (C.c_uint8 * max(1, len(to)))(*to)
+            _check(lib().fhe_str_replace_clear(self.engine.handle, _ptr(a), a_cap, fb, tb, len(frm), _ptr(out)))
+        else:
+            frm, f_cap = self._cap(frm)
+            to, t_cap = self._cap(to)
+            if f_cap != t_cap:
+                raise FheError("replace: `from` and `to` must have the same capacity")
+            both = np.concatenate([frm, to])
+            _check(lib().fhe_str_replace(self.engine.handle, _ptr(a), a_cap, _ptr(both), f_cap, _ptr(out)))
         return out
 
     def to_upper(self, a): return self._unary("to_upper", a)

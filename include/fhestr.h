@@ -149,7 +149,7 @@ int fhe_plan_gather_outputs_dev(fhe_plan *plan, const uint64_t *d_pool, uint64_t
  * blocks, little endian (integer/block_decomposition.rs:119-144): cap * blocks * (kN+1) u64.
  * Results decrypt to what the clear-text function gives on the unpadded ASCII strings.
  * op in {"eq","ne","starts_with","ends_with","contains","find"} (+ "_clear" suffix for a clear
- * pattern) or {"to_upper","to_lower"}.  Outputs: one 0/1 block; find: found block then
+ * pattern) or {"to_upper","to_lower","trim_start","trim_end","strip","replace","replace_clear"}.  Outputs: one 0/1 block; find: found block then
  * ceil(log_msg_mod(cap+1)) index digits (little endian); case ops: the whole string. */
 int fhe_str_plan_create(fhe_engine *eng, const char *op, uint32_t a_cap, uint32_t b_cap,
                         const uint8_t *clear, uint32_t clear_len, uint32_t world, fhe_plan **out);
@@ -167,6 +167,17 @@ FHE_STR_BINARY_DECL(starts_with)
 FHE_STR_BINARY_DECL(ends_with)
 FHE_STR_BINARY_DECL(contains)
 FHE_STR_BINARY_DECL(find)
+/* whitespace = ASCII 9..13 and 32; results are re-padded with zeros (whole string returned) */
+int fhe_str_trim_start(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
+int fhe_str_trim_end(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
+int fhe_str_strip(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
+/* replace every leftmost non-overlapping occurrence of `from` by `to` (equal lengths, so the string
+ * keeps its length).  Encrypted form: from_to = pat_cap chars of `from` then pat_cap chars of `to`,
+ * neither padded.  Plan op names: "replace" (b_cap = 2*pat_cap) / "replace_clear" (clear = from||to). */
+int fhe_str_replace(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const uint64_t *from_to,
+                    uint32_t pat_cap, uint64_t *out);
+int fhe_str_replace_clear(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const uint8_t *from,
+                          const uint8_t *to, uint32_t pat_len, uint64_t *out);
 int fhe_str_to_upper(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
 int fhe_str_to_lower(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
 

@@ -84,6 +84,43 @@ def test_case_conversion(toy_k1, s):
     assert fhestr.blocks_to_string(P, _dec(toy_k1, ops.to_lower(es))) == s.lower().rstrip(b"\0")
 
 
+@pytest.mark.parametrize("s", [b"  hi  ", b"\t a b\n", b"abc", b"    ", b""])
+def test_trim_ops(toy_k1, s):
+    import fhestr
+    ops = _ops(toy_k1)
+    P = gpu_engine(toy_k1).params
+    es = _enc(toy_k1, s, 8)
+    assert fhestr.blocks_to_string(P, _dec(toy_k1, ops.trim_end(es))) == s.rstrip()
+    assert fhestr.blocks_to_string(P, _dec(toy_k1, ops.trim_start(es))) == s.lstrip()
+    assert fhestr.blocks_to_string(P, _dec(toy_k1, ops.strip(es))) == s.strip()
+
+
+@pytest.mark.parametrize("s,frm,to", [(b"abcabc", b"bc", b"XY"), (b"aaaa", b"aa", b"bc"), (b"aaa", b"aa", b"xy"),
+                                       (b"abababab", b"aba", b"xyz")])
+def test_replace(toy_k1, s, frm, to):
+    import fhestr
+    ops = _ops(toy_k1)
+    P = gpu_engine(toy_k1).params
+    es = _enc(toy_k1, s, 8)
+    want = s.replace(frm, to)
+    assert fhestr.blocks_to_string(P, _dec(toy_k1, ops.replace(es, frm, to))) == want
+    enc_out = ops.replace(es, _enc(toy_k1, frm, len(frm)), _enc(toy_k1, to, len(to)))
+    assert fhestr.blocks_to_string(P, _dec(toy_k1, enc_out)) == want
+
+
+def test_p22_replace_to_lower_strip_64_chars(p22):
+    """BASELINE.json config 5 flavour on the real parameter set (PARAM_MESSAGE_2_CARRY_2; the
+    reference's 4_4 set has N = 32768 which this round's kernels do not cover -- DESIGN.md)."""
+    import fhestr
+    ops = _ops(p22)
+    P = gpu_engine(p22).params
+    s = b"  The Quick brown FOX jumps over the lazy dog; the end.   "
+    es = _enc(p22, s, 64)
+    assert fhestr.blocks_to_string(P, _dec(p22, ops.to_lower(es))) == s.lower()
+    assert fhestr.blocks_to_string(P, _dec(p22, ops.replace(es, b"the ", b"THAT"))) == s.replace(b"the ", b"THAT")
+    assert fhestr.blocks_to_string(P, _dec(p22, ops.strip(es))) == s.strip()
+
+
 def test_plan_matches_oracle_execution(toy_k1):
     """Same plan, same inputs: GPU executor vs the oracle stepping through the exported levels."""
     import fhestr

@@ -62,6 +62,29 @@ def test_case_ops_offline_plan_vs_python(toy_k1, s):
     assert fhestr.blocks_to_string(P, _run(toy_k1, "to_lower", s, None)) == s.lower()
 
 
+@pytest.mark.parametrize("s", [b"  hi  ", b"\t a b\n", b"abc", b"    ", b"", b" x", b"x \r\n"])
+def test_trim_ops_offline_plan_vs_python(toy_k1, s):
+    import fhestr
+    P = to_fhestr_params(O.TOY_K1)
+    assert fhestr.blocks_to_string(P, _run(toy_k1, "trim_end", s, None)) == s.rstrip()
+    assert fhestr.blocks_to_string(P, _run(toy_k1, "trim_start", s, None)) == s.lstrip()
+    assert fhestr.blocks_to_string(P, _run(toy_k1, "strip", s, None)) == s.strip()
+
+
+@pytest.mark.parametrize("s,frm,to", [(b"abcabc", b"bc", b"XY"), (b"aaaa", b"aa", b"bc"), (b"aaa", b"aa", b"xy"),
+                                       (b"hello", b"zz", b"yy"), (b"abababab", b"aba", b"xyz"), (b"", b"a", b"b")])
+def test_replace_offline_plan_vs_python(toy_k1, s, frm, to):
+    import fhestr
+    P = to_fhestr_params(O.TOY_K1)
+    want = s.replace(frm, to)
+    got = fhestr.blocks_to_string(P, _run(toy_k1, "replace", s, ("clear", frm + to)))
+    assert got == want, ("clear", got, want)
+    plan = _plan("replace", 8, 2 * len(frm))
+    inputs = np.concatenate([_enc(toy_k1, s, 8), _enc(toy_k1, frm, len(frm)), _enc(toy_k1, to, len(to))])
+    got = fhestr.blocks_to_string(P, toy_k1.ck.decrypt_many(run_with_oracle(plan, inputs, toy_k1.sk)))
+    assert got == want, ("encrypted", got, want)
+
+
 def test_plan_shapes_match_survey_counts():
     # eq enc-enc 256 chars = 1024 + 69 + 5 + 1 PBS, depth 4; enc-clear = 551
     info = _plan("eq", 256, 256).info()
