@@ -11,7 +11,8 @@
 //                      bivariate_pbs.rs:167-182) applied to whole batches.
 //
 // Keyswitch mapping (HBM-streaming integer work, no MFMA): a workgroup owns a tile of
-// KS_COLS output columns x KS_S samples x KS_IC input coefficients.  Every KSK row segment is
+// KS_COLS output columns x KS_S samples x KS_IC input coefficients (the kernel is bound by KSK reads
+// out of L2 / Infinity Cache: 60.9 MB x ceil(B / KS_S) per launch, hence the wide sample tile).  Every KSK row segment is
 // read once per tile with 8-byte-per-lane coalesced loads and reused from a VGPR for KS_S samples;
 // the signed digits of the tile are produced once into LDS and broadcast-read.  Digits are biased
 // to unsigned (d' = d + B/2) so that each multiply-accumulate is one v_mad_u64_u32 plus one
@@ -26,7 +27,7 @@
 namespace fhe {
 
 constexpr int KS_COLS = 256;  // threads per workgroup == output columns per tile
-constexpr int KS_S = 16;      // samples per tile (digits of one (i,lv) fit one 16-byte LDS read)
+constexpr int KS_S = 16;      // samples per tile (digits of one (i,lv) = one 16-byte LDS broadcast read)
 constexpr int KS_IC = 64;     // input coefficients per tile
 
 struct KeyswitchArgs {
@@ -77,8 +78,12 @@ __global__ void __launch_bounds__(KS_COLS) keyswitch_kernel(KeyswitchArgs a) {
     const uint64_t* kp = a.ksk + ((size_t)i0 * L) * a.out_size + ccol;
     for (uint32_t r = 0; r < icount * L; r++) {
         const uint64_t kv = kp[(size_t)r * a.out_size];
-        const uint4 dq = *reinterpret_cast<const uint4*>(ks_smem + (size_t)r * KS_S);
-        const uint32_t dw[4] = {dq.x, dq.y, dq.z, dq.w};
+        uint32_t dw[KS_S / 4];
+#pragma unroll
+        for (int q = 0; q < KS_S / 16; q++) {
+            const uint4 dq = *reinterpret_cast<const uint4*>(ks_smem + (size_t)r * KS_S + q * 16);
+            dw[4 * q + 0] = dq.x; dw[4 * q + 1] = dq.y; dw[4 * q + 2] = dq.z; dw[4 * q + 3] = dq.w;
+        }
         sumkv += kv;
 #pragma unroll
         for (int s = 0; s < KS_S; s++) {
