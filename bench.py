@@ -48,6 +48,10 @@ def cpu_baseline(P, bsk, ksk, cts, lut_tables, lut_sel):
     op = O.Params(P.n, P.k, P.N, P.pbs_base_log, P.pbs_level, P.ks_base_log, P.ks_level,
                   P.msg_mod, P.carry_mod, P.lwe_std, P.glwe_std, P.name)
     cores = min(os.cpu_count() or 1, 16)
+    try:   # rebuild the checker for this host's ISA (AVX-512 where present); falls back to the shipped build
+        O.build(force=True, arch="native")
+    except Exception:
+        pass
     L = O.lib()
     fbsk = np.zeros(bsk.size, dtype=np.float64)
     L.orc_bsk_to_fourier(C.byref(op.c()), bsk, fbsk)

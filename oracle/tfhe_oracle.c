@@ -120,12 +120,21 @@ int64_t orc_f64_to_i64(double x) {
     return (int64_t)x;
 }
 
-/* core_crypto/commons/math/torus/mod.rs:72-78 (FromTorus<f64> for u64).
- * Rust's f64::round rounds half away from zero == C round(). */
+/* Rust's f64::round == C round(): ties away from zero.  Inlined (trunc compiles to one roundsd;
+ * libm's round() is an out-of-line call that dominated the oracle's run time); exact for all inputs. */
+static inline double round_half_away(double x) {
+    double t = trunc(x);
+    double d = x - t; /* exact */
+    if (d >= 0.5) return t + 1.0;
+    if (d <= -0.5) return t - 1.0;
+    return t;
+}
+
+/* core_crypto/commons/math/torus/mod.rs:72-78 (FromTorus<f64> for u64). */
 uint64_t orc_from_torus(double x) {
-    double fract = x - round(x);
+    double fract = x - round_half_away(x);
     fract *= 18446744073709551616.0; /* 2^64 */
-    fract = round(fract);
+    fract = round_half_away(fract);
     return (uint64_t)orc_f64_to_i64(fract);
 }
 
@@ -180,10 +189,11 @@ void orc_sample_extract(const orc_params *p, const uint64_t *acc, uint64_t *lwe)
  * in the last bits ("parity unpinned"); all consumers only multiply pointwise and transform back.
  * ---------------------------------------------------------------------------------------- */
 struct orc_fft {
-    uint32_t N, n;     /* n = N/2 */
+    uint32_t N, n, lg;       /* n = N/2 = 2^lg */
     double *tw_re, *tw_im;   /* twisties */
-    double *w_re, *w_im;     /* exp(-2*pi*i*j/n), j < n/2 */
+    double *st_re, *st_im;   /* per-stage twiddles, stage with half-size h stored at offset h: exp(-2 pi i j / (2h)) */
     uint32_t *rev;
+    double *sc_re, *sc_im;   /* scratch planes (one plan per thread) */
 };
 
 orc_fft *orc_fft_new(uint32_t N) {
@@ -191,23 +201,27 @@ orc_fft *orc_fft_new(uint32_t N) {
     uint32_t n = N / 2;
     f->N = N;
     f->n = n;
-    f->tw_re = (double *)malloc(sizeof(double) * n);
-    f->tw_im = (double *)malloc(sizeof(double) * n);
-    f->w_re = (double *)malloc(sizeof(double) * (n / 2 + 1));
-    f->w_im = (double *)malloc(sizeof(double) * (n / 2 + 1));
+    f->tw_re = (double *)aligned_alloc(64, sizeof(double) * n);
+    f->tw_im = (double *)aligned_alloc(64, sizeof(double) * n);
+    f->st_re = (double *)aligned_alloc(64, sizeof(double) * 2 * n);
+    f->st_im = (double *)aligned_alloc(64, sizeof(double) * 2 * n);
+    f->sc_re = (double *)aligned_alloc(64, sizeof(double) * n);
+    f->sc_im = (double *)aligned_alloc(64, sizeof(double) * n);
     f->rev = (uint32_t *)malloc(sizeof(uint32_t) * n);
     double unit = M_PI / (2.0 * (double)n);
     for (uint32_t i = 0; i < n; i++) {
         f->tw_re[i] = cos((double)i * unit);
         f->tw_im[i] = sin((double)i * unit);
     }
-    for (uint32_t i = 0; i < n / 2 + 1; i++) {
-        double a = -2.0 * M_PI * (double)i / (double)n;
-        f->w_re[i] = cos(a);
-        f->w_im[i] = sin(a);
-    }
+    for (uint32_t h = 1; h < n; h <<= 1)
+        for (uint32_t j = 0; j < h; j++) {
+            double a = -M_PI * (double)j / (double)h;
+            f->st_re[h + j] = cos(a);
+            f->st_im[h + j] = sin(a);
+        }
     uint32_t lg = 0;
     while ((1u << lg) < n) lg++;
+    f->lg = lg;
     for (uint32_t i = 0; i < n; i++) {
         uint32_t r = 0;
         for (uint32_t b = 0; b < lg; b++)
@@ -219,40 +233,36 @@ orc_fft *orc_fft_new(uint32_t N) {
 
 void orc_fft_free(orc_fft *f) {
     if (!f) return;
-    free(f->tw_re);
-    free(f->tw_im);
-    free(f->w_re);
-    free(f->w_im);
-    free(f->rev);
+    free(f->tw_re); free(f->tw_im); free(f->st_re); free(f->st_im);
+    free(f->sc_re); free(f->sc_im); free(f->rev);
     free(f);
 }
 
-/* in-place complex FFT on interleaved data; sign=-1 forward (uses w), +1 inverse (conj w) */
-static void cfft(const orc_fft *f, double *d, int sign) {
+/* in-place complex FFT on split planes (bit-reversed input order expected by the caller: the
+ * data in re/im must already be permuted by f->rev); sign < 0 forward, > 0 inverse (conj twiddles).
+ * Plain radix-2 decimation in time; the j loops are contiguous so gcc vectorises them. */
+static void cfft_planes(const orc_fft *f, double *restrict re, double *restrict im, int sign) {
     const uint32_t n = f->n;
-    for (uint32_t i = 0; i < n; i++) {
-        uint32_t r = f->rev[i];
-        if (r > i) {
-            double tr = d[2 * i], ti = d[2 * i + 1];
-            d[2 * i] = d[2 * r];
-            d[2 * i + 1] = d[2 * r + 1];
-            d[2 * r] = tr;
-            d[2 * r + 1] = ti;
-        }
-    }
-    for (uint32_t len = 2; len <= n; len <<= 1) {
-        uint32_t half = len / 2, step = n / len;
-        for (uint32_t s = 0; s < n; s += len) {
-            for (uint32_t j = 0; j < half; j++) {
-                double wr = f->w_re[j * step];
-                double wi = sign < 0 ? f->w_im[j * step] : -f->w_im[j * step];
-                double *a = d + 2 * (s + j), *b = d + 2 * (s + j + half);
-                double xr = b[0] * wr - b[1] * wi;
-                double xi = b[0] * wi + b[1] * wr;
-                b[0] = a[0] - xr;
-                b[1] = a[1] - xi;
-                a[0] += xr;
-                a[1] += xi;
+    for (uint32_t h = 1; h < n; h <<= 1) {
+        const double *restrict wr = f->st_re + h;
+        const double *restrict wi0 = f->st_im + h;
+        for (uint32_t s = 0; s < n; s += 2 * h) {
+            double *restrict ar = re + s, *restrict ai = im + s;
+            double *restrict br = re + s + h, *restrict bi = im + s + h;
+            if (sign < 0) {
+                for (uint32_t j = 0; j < h; j++) {
+                    double xr = br[j] * wr[j] - bi[j] * wi0[j];
+                    double xi = br[j] * wi0[j] + bi[j] * wr[j];
+                    br[j] = ar[j] - xr; bi[j] = ai[j] - xi;
+                    ar[j] += xr; ai[j] += xi;
+                }
+            } else {
+                for (uint32_t j = 0; j < h; j++) {
+                    double xr = br[j] * wr[j] + bi[j] * wi0[j];
+                    double xi = bi[j] * wr[j] - br[j] * wi0[j];
+                    br[j] = ar[j] - xr; bi[j] = ai[j] - xi;
+                    ar[j] += xr; ai[j] += xi;
+                }
             }
         }
     }
@@ -260,13 +270,19 @@ static void cfft(const orc_fft *f, double *d, int sign) {
 
 static void fft_forward(const orc_fft *f, double *out, const uint64_t *poly, double scale) {
     const uint32_t n = f->n;
+    double *re = f->sc_re, *im = f->sc_im;
     for (uint32_t j = 0; j < n; j++) {
-        double re = (double)(int64_t)poly[j] * scale;       /* into_signed().cast_into() */
-        double im = (double)(int64_t)poly[j + n] * scale;
-        out[2 * j] = re * f->tw_re[j] - im * f->tw_im[j];
-        out[2 * j + 1] = re * f->tw_im[j] + im * f->tw_re[j];
+        double a = (double)(int64_t)poly[j] * scale;       /* into_signed().cast_into() */
+        double b = (double)(int64_t)poly[j + n] * scale;
+        uint32_t r = f->rev[j];
+        re[r] = a * f->tw_re[j] - b * f->tw_im[j];
+        im[r] = a * f->tw_im[j] + b * f->tw_re[j];
     }
-    cfft(f, out, -1);
+    cfft_planes(f, re, im, -1);
+    for (uint32_t j = 0; j < n; j++) {
+        out[2 * j] = re[j];
+        out[2 * j + 1] = im[j];
+    }
 }
 
 void orc_fft_forward_as_integer(const orc_fft *f, double *out, const uint64_t *poly) {
@@ -278,14 +294,20 @@ void orc_fft_forward_as_torus(const orc_fft *f, double *out, const uint64_t *pol
 
 void orc_fft_add_backward_as_torus(const orc_fft *f, uint64_t *poly, double *d) {
     const uint32_t n = f->n;
-    cfft(f, d, +1);
+    double *re = f->sc_re, *im = f->sc_im;
+    for (uint32_t j = 0; j < n; j++) {
+        uint32_t r = f->rev[j];
+        re[r] = d[2 * j];
+        im[r] = d[2 * j + 1];
+    }
+    cfft_planes(f, re, im, +1);
     const double norm = 1.0 / (double)n;
     for (uint32_t j = 0; j < n; j++) {
         double wr = f->tw_re[j] * norm, wi = -f->tw_im[j] * norm;
-        double re = d[2 * j] * wr - d[2 * j + 1] * wi;
-        double im = d[2 * j] * wi + d[2 * j + 1] * wr;
-        poly[j] += orc_from_torus(re);
-        poly[j + n] += orc_from_torus(im);
+        double a = re[j] * wr - im[j] * wi;
+        double b = re[j] * wi + im[j] * wr;
+        poly[j] += orc_from_torus(a);
+        poly[j + n] += orc_from_torus(b);
     }
 }
 
@@ -307,10 +329,11 @@ void orc_add_external_product_fft(const orc_params *p, const orc_fft *f, uint64_
                                   const double *fggsw, const uint64_t *glwe) {
     const uint32_t N = p->N, k1 = p->k + 1, L = p->pbs_level, b = p->pbs_base_log;
     const size_t G = (size_t)k1 * N;
-    uint64_t *state = (uint64_t *)malloc(G * sizeof(uint64_t));
-    uint64_t *digit = (uint64_t *)malloc(G * sizeof(uint64_t));
-    double *fourier = (double *)malloc(N * sizeof(double));
-    double *outf = (double *)calloc((size_t)k1 * N, sizeof(double));
+    /* one allocation per call (the reference carves these from a PodStack, ggsw.rs:502-508) */
+    uint64_t *state = (uint64_t *)malloc((2 * G) * sizeof(uint64_t) + ((size_t)N + (size_t)k1 * N) * sizeof(double));
+    uint64_t *digit = state + G;
+    double *fourier = (double *)(digit + G);
+    double *outf = fourier + N;
     const uint64_t mod_b_mask = (1ULL << b) - 1;
     /* :514-518 + fft64/math/decomposition.rs:33-35 */
     for (size_t j = 0; j < G; j++)
@@ -343,9 +366,6 @@ void orc_add_external_product_fft(const orc_params *p, const orc_fft *f, uint64_
     for (uint32_t col = 0; col < k1; col++) /* :585-597 */
         orc_fft_add_backward_as_torus(f, out + (size_t)col * N, outf + (size_t)col * N);
     free(state);
-    free(digit);
-    free(fourier);
-    free(outf);
 }
 
 /* Exact-integer twin: out[col] += sum_lvl sum_row digit[lvl][row] (*) ggsw_std[lvl][row][col]
