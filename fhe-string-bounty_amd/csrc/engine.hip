@@ -15,6 +15,7 @@
 
 #include "lwe_kernels.hip.h"
 #include "pbs_kernels.hip.h"
+#include "pbs_large_kernels.hip.h"
 
 namespace fhe {
 
@@ -36,6 +37,9 @@ int fail(const std::string& msg) {
 struct BrVariant {
     int logN, k1, L, logR;
     bool wide;          // true: every thread carries all k+1 polynomials (blind_rotate_wide_kernel)
+    bool large;         // true: four-step FFT through an HBM workspace (blind_rotate_large_kernel)
+    size_t ws_bytes;    // per-LWE workspace (large only)
+    size_t convert_ws;  // per-workgroup workspace of the conversion kernel (large only)
     int threads;
     int convert_threads;
     size_t lds_bytes;
@@ -48,7 +52,8 @@ template <int LOGN, int LOGR, int K1, int L>
 BrVariant make_variant() {
     using CFG = BrCfg<LOGN, LOGR, K1, L>;
     BrVariant v;
-    v.logN = LOGN; v.k1 = K1; v.L = L; v.logR = LOGR; v.wide = false;
+    v.logN = LOGN; v.k1 = K1; v.L = L; v.logR = LOGR; v.wide = false; v.large = false;
+    v.ws_bytes = 0; v.convert_ws = 0;
     v.threads = CFG::THREADS;
     v.convert_threads = CFG::THREADS;
     v.lds_bytes = CFG::LDS_FIXED;   // + 4*n for the modulus-switched mask
@@ -69,6 +74,22 @@ BrVariant make_wide_variant() {
     return v;
 }
 
+template <int LOGN, int K1, int L>
+BrVariant make_large_variant() {
+    using CFG = BrLargeCfg<LOGN, K1, L>;
+    BrVariant v;
+    v.logN = LOGN; v.k1 = K1; v.L = L; v.logR = 3; v.wide = false; v.large = true;
+    v.threads = CFG::THREADS;
+    v.convert_threads = CFG::THREADS;
+    v.lds_bytes = CFG::LDS_BYTES;
+    v.convert_lds = CFG::LDS_BYTES;
+    v.ws_bytes = CFG::WS_BYTES;
+    v.convert_ws = (size_t)CFG::P * 16;
+    v.rotate_fn = reinterpret_cast<const void*>(&blind_rotate_large_kernel<LOGN, K1, L>);
+    v.convert_fn = reinterpret_cast<const void*>(&bsk_convert_large_kernel<LOGN, K1, L>);
+    return v;
+}
+
 static const std::vector<BrVariant>& variants() {
     static const std::vector<BrVariant> v = {
         // PARAM_MESSAGE_2_CARRY_2_KS_PBS: N=2048, k=1, l=1  (first entry of a shape = default)
@@ -81,6 +102,8 @@ static const std::vector<BrVariant>& variants() {
         // toy shapes used by the fast tests
         make_variant<8, 2, 2, 2>(), make_variant<7, 2, 3, 1>(),
         make_wide_variant<8, 2, 2, 2>(), make_wide_variant<7, 2, 3, 1>(),
+        // polynomial sizes beyond the LDS: PARAM_MESSAGE_3_CARRY_3 (N = 8192) and PARAM_MESSAGE_4_CARRY_4 (N = 32768)
+        make_large_variant<13, 2, 2>(), make_large_variant<15, 2, 2>(),
     };
     return v;
 }
@@ -140,7 +163,7 @@ Engine::~Engine() {
     if (stream) (void)hipStreamSynchronize(stream);
     auto rel = [](void* ptr) { if (ptr) (void)hipFree(ptr); };
     rel(d_ksk); rel(d_fbsk); rel(d_luts); rel(d_in); rel(d_small); rel(d_out); rel(d_idx);
-    rel(d_pool); rel(d_meta);
+    rel(d_pool); rel(d_meta); rel(d_ws);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ring) if (e) (void)hipEventDestroy(e);
     if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -206,12 +229,23 @@ int Engine::load_keys(const uint64_t* bsk_std, const uint64_t* ksk) {
     HIP_TRY(hipMemcpyAsync(d_std, bsk_std, bsk_len * 8, hipMemcpyHostToDevice, stream));
     const uint32_t n_polys = (uint32_t)(bsk_len / p.N);
     const uint32_t k1 = p.k + 1;
-    void* args[] = {(void*)&d_std, (void*)&d_fbsk, (void*)&n_polys};
     HIP_TRY(hipFuncSetAttribute(variant->convert_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)variant->convert_lds));
-    HIP_TRY(hipLaunchKernel(variant->convert_fn, dim3((n_polys + k1 - 1) / k1), dim3(variant->convert_threads),
-                            args, variant->convert_lds, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    if (variant->large) {
+        const uint32_t blocks = n_polys < (uint32_t)cu_count ? n_polys : (uint32_t)cu_count;
+        void* d_cws = nullptr;
+        HIP_TRY(hipMalloc(&d_cws, (size_t)blocks * variant->convert_ws));
+        void* args[] = {(void*)&d_std, (void*)&d_fbsk, (void*)&n_polys, (void*)&d_cws};
+        HIP_TRY(hipLaunchKernel(variant->convert_fn, dim3(blocks), dim3(variant->convert_threads), args,
+                                variant->convert_lds, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipFree(d_cws));
+    } else {
+        void* args[] = {(void*)&d_std, (void*)&d_fbsk, (void*)&n_polys};
+        HIP_TRY(hipLaunchKernel(variant->convert_fn, dim3((n_polys + k1 - 1) / k1), dim3(variant->convert_threads),
+                                args, variant->convert_lds, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
     HIP_TRY(hipFree(d_std));
     HIP_TRY(hipFuncSetAttribute(variant->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(variant->lds_bytes + (size_t)p.n * 4)));
@@ -300,6 +334,13 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
     // one LWE per CU or fewer: spread it over more threads; above that: the compact layout that
     // lets two LWEs share a CU
     const BrVariant* v = count > (uint32_t)cu_count ? variant_large : variant;
+    if (v->large) {
+        if (ensure(&d_ws, &cap_ws, (size_t)count * v->ws_bytes)) return 1;
+        BlindRotateLargeArgs la{a, reinterpret_cast<unsigned char*>(d_ws)};
+        void* largs[] = {(void*)&la};
+        HIP_TRY(hipLaunchKernel(v->rotate_fn, dim3(count), dim3(v->threads), largs, v->lds_bytes, stream));
+        return 0;
+    }
     HIP_TRY(hipLaunchKernel(v->rotate_fn, dim3(count), dim3(v->threads), args,
                             v->lds_bytes + (size_t)p.n * 4, stream));
     return 0;

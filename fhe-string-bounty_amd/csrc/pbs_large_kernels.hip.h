@@ -1,0 +1,342 @@
+// pbs_large_kernels.hip.h -- blind rotation for polynomial sizes whose accumulator and spectra do
+// not fit the 160 KB LDS of a CU (N >= 8192: PARAM_MESSAGE_3_CARRY_3 N = 8192, PARAM_MESSAGE_4_CARRY_4
+// N = 32768, shortint/parameters/mod.rs:853-867,1063-1077).
+//
+// Same algorithm as pbs_kernels.hip.h (fft64/crypto/bootstrap.rs:242-364, ggsw.rs:477-598), other
+// data placement: one workgroup per LWE keeps its accumulator (k+1)*N u64 and two spectrum buffers
+// in a private HBM/L2 workspace, and the size-P = N/2 complex FFT is done "four-step": P = P1*P2,
+//   phase 1  P2 column transforms of size P1 (stride P2) + twiddle w_P^{q1*b}      -> tmp
+//   phase 2  P1 row transforms of size P2 (contiguous), Fourier multiply-accumulate against the
+//            GGSW rows in registers, inverse row transforms, conjugate twiddle      -> tmp2
+//   phase 3  P2 inverse column transforms, untwist, torus rounding, accumulate into acc
+// Each size-P1 / size-P2 transform is the in-register radix-8 kernel of negacyclic_fft.hip.h run by
+// 16 (or 8) threads with wave-local LDS exchanges; four adjacent columns share a wavefront quarter
+// so that every strided access still moves whole 64-byte sectors.  Three workgroup barriers per CMUX
+// step order the phases (global memory is coherent inside a workgroup: one CU, one vector L1).
+// The spectrum order is whatever the two in-place transforms leave; the Fourier key is converted
+// with the same code (bsk_convert_large_kernel), so the pointwise product needs no reordering.
+#pragma once
+#include "pbs_kernels.hip.h"
+
+namespace fhe {
+
+template <int LOGN, int K1, int L>
+struct BrLargeCfg {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int LOGP = LOGN - 1;
+    static constexpr int P = 1 << LOGP;
+    static constexpr int LOGP1 = (LOGP + 1) / 2, LOGP2 = LOGP / 2;
+    static constexpr int P1 = 1 << LOGP1, P2 = 1 << LOGP2;
+    using PA = FftPlan<LOGP1, 3>;      // column transforms (size P1)
+    using PB = FftPlan<LOGP2, 3>;      // row transforms (size P2)
+    static constexpr int R = 8;
+    static constexpr int TA = PA::T, TB = PB::T;
+    static constexpr int THREADS = 512;
+    static constexpr int SUBS_A = THREADS / TA, SUBS_B = THREADS / TB;   // transforms in flight
+    static constexpr int SLOTS_A = 2 * P1 + 4, SLOTS_B = 2 * P2 + 4;     // LDS slots per transform
+    static constexpr size_t LDS_BYTES =
+        (size_t)(SUBS_A * SLOTS_A > SUBS_B * SLOTS_B ? SUBS_A * SLOTS_A : SUBS_B * SLOTS_B) * 8;
+    // per-LWE workspace in HBM (bytes): acc | tmp[L*K1][P] c64 | tmp2[K1][P] c64
+    static constexpr size_t WS_ACC = (size_t)K1 * N * 8;
+    static constexpr size_t WS_TMP = (size_t)L * K1 * P * 16;
+    static constexpr size_t WS_TMP2 = (size_t)K1 * P * 16;
+    static constexpr size_t WS_BYTES = WS_ACC + WS_TMP + WS_TMP2;
+};
+
+// frequency index of the value an in-place DIF transform leaves at last-pass address A
+template <class PL>
+__device__ __forceinline__ int freq_of_addr(int A) {
+    int q = 0, weight = 1;
+#pragma unroll
+    for (int s = 0; s < PL::NP; s++) {
+        const int lr = PL::log_radix(s);
+        const int lS1 = PL::log_S(s) - lr;
+        const int digit = (A >> lS1) & ((1 << lr) - 1);
+        q += digit * weight;
+        weight <<= lr;
+    }
+    return q;
+}
+
+// last-pass address of register slot rho of thread tau
+template <class PL>
+__device__ __forceinline__ int slot_addr(int tau, int rho) {
+    constexpr int s = PL::NP - 1;
+    const int rr = 1 << PL::log_radix(s);
+    return pass_addr<PL>(s, tau, rho / rr, rho % rr);
+}
+
+__device__ __forceinline__ cplx unit_root(double turns) {   // e^{2 pi i turns}
+    double sn, cs;
+    sincospi(2.0 * turns, &sn, &cs);
+    cplx w; w.re = cs; w.im = sn;
+    return w;
+}
+
+// ---- phase helpers -------------------------------------------------------------------------------
+// column transform forward: x[m] holds point (a = tau + TA*m, column b); result slot rho is written to
+// dst[slot_addr * P2 + b] after the inter-step twiddle w_P^{-q1*b} (forward sign convention e^{-2 pi i})
+template <class CFG>
+__device__ __forceinline__ void column_forward_store(cplx* x, const FftConsts<typename CFG::PA>& fc, double* re,
+                                                     double* im, int tau, int b, double2* dst) {
+    using PA = typename CFG::PA;
+    fft_forward<PA>(x, fc, re, im, tau);
+#pragma unroll
+    for (int rho = 0; rho < CFG::R; rho++) {
+        const int A = slot_addr<PA>(tau, rho);
+        const int q1 = freq_of_addr<PA>(A);
+        const cplx w = unit_root(-(double)((q1 * b) & (CFG::P - 1)) / (double)CFG::P);
+        const cplx v = cmul(x[rho], w);
+        dst[(size_t)A * CFG::P2 + b] = make_double2(v.re, v.im);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int LOGN, int K1, int L>
+__global__ void __launch_bounds__((BrLargeCfg<LOGN, K1, L>::THREADS))
+bsk_convert_large_kernel(const uint64_t* __restrict__ bsk_std, double* __restrict__ fbsk, uint32_t n_polys,
+                         double2* __restrict__ workspace /* gridDim.x * P c64 */) {
+    using CFG = BrLargeCfg<LOGN, K1, L>;
+    using PA = typename CFG::PA;
+    using PB = typename CFG::PB;
+    constexpr int N = CFG::N, P = CFG::P, P1 = CFG::P1, P2 = CFG::P2, R = CFG::R;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    const int tid = threadIdx.x;
+    const int subA = tid / CFG::TA, tauA = tid % CFG::TA;
+    const int subB = tid / CFG::TB, tauB = tid % CFG::TB;
+    FftConsts<PA> fca;
+    FftConsts<PB> fcb;
+    fft_init_consts<PA>(fca, tauA);
+    fft_init_consts<PB>(fcb, tauB);
+    double2* tmp = workspace + (size_t)blockIdx.x * P;
+    for (uint32_t poly = blockIdx.x; poly < n_polys; poly += gridDim.x) {
+        const uint64_t* src = bsk_std + (size_t)poly * N;
+        for (int b0 = 0; b0 < P2; b0 += CFG::SUBS_A) {
+            const int b = b0 + subA;
+            cplx x[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                const int j = (tauA + CFG::TA * m) * P2 + b;
+                cplx z;   // forward_as_torus (fft/mod.rs:197-218) with the inverse's 1/P folded in
+                z.re = i64_to_f64(src[j]) * (5.421010862427522e-20 / P);
+                z.im = i64_to_f64(src[j + P]) * (5.421010862427522e-20 / P);
+                x[m] = cmul(z, unit_root((double)j / (double)(2 * N)));   // twisty e^{i pi j / N}
+            }
+            column_forward_store<CFG>(x, fca, lds + (size_t)subA * CFG::SLOTS_A, lds + (size_t)subA * CFG::SLOTS_A + P1 + 2,
+                                      tauA, b, tmp);
+        }
+        __syncthreads();
+        double2* out = reinterpret_cast<double2*>(fbsk) + (size_t)poly * P;
+        for (int r0 = 0; r0 < P1; r0 += CFG::SUBS_B) {
+            const int r = r0 + subB;
+            cplx x[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                const double2 v = tmp[(size_t)r * P2 + tauB + CFG::TB * m];
+                x[m].re = v.x; x[m].im = v.y;
+            }
+            fft_forward<PB>(x, fcb, lds + (size_t)subB * CFG::SLOTS_B, lds + (size_t)subB * CFG::SLOTS_B + P2 + 2, tauB);
+#pragma unroll
+            for (int rho = 0; rho < R; rho++) out[(size_t)r * P2 + rho * CFG::TB + tauB] = make_double2(x[rho].re, x[rho].im);
+        }
+        __syncthreads();
+    }
+}
+
+struct BlindRotateLargeArgs {
+    BlindRotateArgs base;
+    unsigned char* workspace;    // batch * WS_BYTES
+};
+
+// ------------------------------------------------------------------------------------------------
+template <int LOGN, int K1, int L>
+__global__ void __launch_bounds__((BrLargeCfg<LOGN, K1, L>::THREADS))
+blind_rotate_large_kernel(BlindRotateLargeArgs la) {
+    using CFG = BrLargeCfg<LOGN, K1, L>;
+    using PA = typename CFG::PA;
+    using PB = typename CFG::PB;
+    constexpr int N = CFG::N, P = CFG::P, P1 = CFG::P1, P2 = CFG::P2, R = CFG::R, NT = CFG::THREADS;
+    const BlindRotateArgs& args = la.base;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    __shared__ uint32_t s_d;   // modulus-switched mask element of the current step
+
+    const int tid = threadIdx.x;
+    const int subA = tid / CFG::TA, tauA = tid % CFG::TA;
+    const int subB = tid / CFG::TB, tauB = tid % CFG::TB;
+    double* areA = lds + (size_t)subA * CFG::SLOTS_A;
+    double* aimA = areA + P1 + 2;
+    double* breB = lds + (size_t)subB * CFG::SLOTS_B;
+    double* bimB = breB + P2 + 2;
+    const uint32_t sample = blockIdx.x;
+    const uint32_t n = args.n;
+    const uint64_t* lwe = args.lwe_small + (size_t)sample * (n + 1);
+    const uint64_t* lut = args.luts + (size_t)(args.lut_idx ? args.lut_idx[sample] : 0) * K1 * N;
+    unsigned char* ws = la.workspace + (size_t)sample * CFG::WS_BYTES;
+    uint64_t* acc = reinterpret_cast<uint64_t*>(ws);                                   // [K1][N]
+    double2* tmp = reinterpret_cast<double2*>(ws + CFG::WS_ACC);                       // [L*K1][P]
+    double2* tmp2 = reinterpret_cast<double2*>(ws + CFG::WS_ACC + CFG::WS_TMP);        // [K1][P]
+    const uint32_t bL = args.base_log * L;
+
+    FftConsts<PA> fca;
+    FftConsts<PB> fcb;
+    fft_init_consts<PA>(fca, tauA);
+    fft_init_consts<PB>(fcb, tauB);
+
+    // acc <- LUT * X^{-ms(body)}
+    {
+        const uint32_t d = modulus_switch(lwe[n], LOGN);
+        const uint32_t rem = d & (N - 1);
+        const bool odd = (d >> LOGN) & 1;
+        for (int e = tid; e < K1 * N; e += NT) {
+            const uint32_t p = e >> LOGN, j = e & (N - 1);
+            const uint32_t src = (j + rem) & (N - 1);
+            const bool neg = ((j + rem) >= (uint32_t)N) != odd;
+            const uint64_t v = lut[(size_t)p * N + src];
+            acc[e] = neg ? (0 - v) : v;
+        }
+    }
+    __syncthreads();
+
+    const double2* fbsk = reinterpret_cast<const double2*>(args.fbsk);
+    constexpr size_t GGSW_ELEMS = (size_t)L * K1 * K1 * P;
+
+    for (uint32_t i = 0; i < n; i++) {
+        if (tid == 0) {
+            const uint64_t a = lwe[i];
+            s_d = a == 0 ? 0xFFFFFFFFu : modulus_switch(a, LOGN);
+        }
+        __syncthreads();
+        const uint32_t d = s_d;
+        if (d == 0xFFFFFFFFu) { __syncthreads(); continue; }
+        const uint32_t rem = d & (N - 1);
+        const bool odd = (d >> LOGN) & 1;
+
+        // ---- phase 1: decompose (acc*X^d - acc), twist, column transforms, twiddle -> tmp ----
+        for (int p = 0; p < K1; p++) {
+            const uint64_t* ap = acc + (size_t)p * N;
+            for (int b0 = 0; b0 < P2; b0 += CFG::SUBS_A) {
+                const int b = b0 + subA;
+                uint32_t st_lo[R], st_hi[R];
+#pragma unroll
+                for (int m = 0; m < R; m++) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const uint32_t j = (tauA + CFG::TA * m) * P2 + b + h * P;
+                        const uint32_t src = (j - rem) & (N - 1);
+                        const bool neg = (j < rem) != odd;
+                        uint64_t v = ap[src];
+                        v = neg ? (0 - v) : v;
+                        const uint32_t st = decomp_init_state(v - ap[j], bL);
+                        if (h == 0) st_lo[m] = st; else st_hi[m] = st;
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < L; it++) {
+                    cplx x[R];
+#pragma unroll
+                    for (int m = 0; m < R; m++) {
+                        const int j = (tauA + CFG::TA * m) * P2 + b;
+                        cplx z;
+                        z.re = (double)decomp_next_digit(st_lo[m], args.base_log);
+                        z.im = (double)decomp_next_digit(st_hi[m], args.base_log);
+                        x[m] = cmul(z, unit_root((double)j / (double)(2 * N)));
+                    }
+                    column_forward_store<CFG>(x, fca, areA, aimA, tauA, b, tmp + (size_t)(it * K1 + p) * P);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: row transforms, multiply-accumulate with the GGSW, inverse row transforms -> tmp2 ----
+        const double2* bk0 = fbsk + (size_t)i * GGSW_ELEMS;
+        for (int r0 = 0; r0 < P1; r0 += CFG::SUBS_B) {
+            const int r = r0 + subB;
+            cplx outf[K1][R];
+#pragma unroll
+            for (int it = 0; it < L; it++) {
+                const int lvl_idx = L - 1 - it;                      // ggsw.rs:524
+#pragma unroll
+                for (int row = 0; row < K1; row++) {
+                    cplx x[R];
+                    const double2* srow = tmp + (size_t)(it * K1 + row) * P + (size_t)r * P2;
+#pragma unroll
+                    for (int m = 0; m < R; m++) {
+                        const double2 v = srow[tauB + CFG::TB * m];
+                        x[m].re = v.x; x[m].im = v.y;
+                    }
+                    fft_forward<PB>(x, fcb, breB, bimB, tauB);
+#pragma unroll
+                    for (int col = 0; col < K1; col++) {
+                        const double2* bk = bk0 + (((size_t)lvl_idx * K1 + row) * K1 + col) * P + (size_t)r * P2;
+#pragma unroll
+                        for (int rho = 0; rho < R; rho++) {
+                            const double2 bv = bk[rho * CFG::TB + tauB];
+                            if (it == 0 && row == 0) {
+                                outf[col][rho].re = bv.x * x[rho].re - bv.y * x[rho].im;
+                                outf[col][rho].im = bv.x * x[rho].im + bv.y * x[rho].re;
+                            } else {
+                                outf[col][rho].re = fma(bv.x, x[rho].re, fma(-bv.y, x[rho].im, outf[col][rho].re));
+                                outf[col][rho].im = fma(bv.x, x[rho].im, fma(bv.y, x[rho].re, outf[col][rho].im));
+                            }
+                        }
+                    }
+                }
+            }
+            const int q1 = freq_of_addr<PA>(r);
+#pragma unroll
+            for (int col = 0; col < K1; col++) {
+                fft_inverse<PB>(outf[col], fcb, breB, bimB, tauB);
+                double2* drow = tmp2 + (size_t)col * P + (size_t)r * P2;
+#pragma unroll
+                for (int m = 0; m < R; m++) {
+                    const int b = tauB + CFG::TB * m;
+                    const cplx w = unit_root((double)((q1 * b) & (P - 1)) / (double)P);   // conj of the forward twiddle
+                    const cplx v = cmul(outf[col][m], w);
+                    drow[b] = make_double2(v.re, v.im);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 3: inverse column transforms, untwist, torus rounding, accumulate ----
+        for (int p = 0; p < K1; p++) {
+            uint64_t* ap = acc + (size_t)p * N;
+            const double2* sp = tmp2 + (size_t)p * P;
+            for (int b0 = 0; b0 < P2; b0 += CFG::SUBS_A) {
+                const int b = b0 + subA;
+                cplx x[R];
+#pragma unroll
+                for (int rho = 0; rho < R; rho++) {
+                    const double2 v = sp[(size_t)slot_addr<PA>(tauA, rho) * P2 + b];
+                    x[rho].re = v.x; x[rho].im = v.y;
+                }
+                fft_inverse<PA>(x, fca, areA, aimA, tauA);
+#pragma unroll
+                for (int m = 0; m < R; m++) {
+                    const int j = (tauA + CFG::TA * m) * P2 + b;
+                    const cplx t = cmul_conj(x[m], unit_root((double)j / (double)(2 * N)));
+                    ap[j] += from_torus(t.re);
+                    ap[j + P] += from_torus(t.im);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // sample extraction at degree 0 (glwe_sample_extraction.rs:121-146)
+    uint64_t* out = args.lwe_out + (size_t)sample * ((size_t)(K1 - 1) * N + 1);
+    for (int e = tid; e < K1 * N; e += NT) {
+        const uint32_t p = e >> LOGN, j = e & (N - 1);
+        const uint64_t v = acc[e];
+        if (p == K1 - 1) {
+            if (j == 0) out[(size_t)(K1 - 1) * N] = v;
+        } else {
+            if (j == 0) out[(size_t)p * N] = v;
+            else out[(size_t)p * N + (N - j)] = 0 - v;
+        }
+    }
+}
+
+}  // namespace fhe

@@ -96,6 +96,9 @@ PARAM_MESSAGE_4_CARRY_4_KS_PBS = Params(996, 1, 32768, 15, 2, 3, 7, 16, 16,
 # Tiny sets for fast tests (NOT secure; noise small enough that decryption is always right).
 TOY_K1 = Params(16, 1, 256, 10, 2, 4, 4, 4, 4, 1e-12, 1e-15, "TOY_K1_N256_L2")
 TOY_K2 = Params(12, 2, 128, 12, 1, 3, 5, 2, 2, 1e-12, 1e-15, "TOY_K2_N128_L1")
+# large-polynomial shapes (PARAM_MESSAGE_3_CARRY_3 / PARAM_MESSAGE_4_CARRY_4 geometry, tiny n)
+TOY_N8192 = Params(8, 1, 8192, 15, 2, 3, 6, 8, 8, 1e-13, 1e-17, "TOY_N8192_L2")
+TOY_N32768 = Params(4, 1, 32768, 15, 2, 3, 7, 16, 16, 1e-13, 1e-17, "TOY_N32768_L2")
 
 _u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")

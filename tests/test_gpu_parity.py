@@ -193,3 +193,32 @@ def test_toy_wide_variants(params, selector):
     cts = ks.ck.encrypt_many(list(range(M)) * 2, O.Rng(5, 5))
     got = eng.apply_lookup_table(cts, np.full(2 * M, lut_id, dtype=np.uint32))
     assert np.array_equal(ks.ck.decrypt_many(got), np.array([M - 1 - m for m in range(M)] * 2))
+
+
+@pytest.mark.parametrize("params", [O.TOY_N8192, O.TOY_N32768], ids=lambda p: p.name)
+def test_large_polynomial_sizes(params):
+    """N = 8192 / 32768 (geometry of PARAM_MESSAGE_3_CARRY_3 / _4_CARRY_4): accumulator and spectra
+    live in an HBM workspace, four-step FFT (pbs_large_kernels.hip.h)."""
+    ks = keyset(params)
+    eng = gpu_engine(ks)
+    M = params.msg_mod * params.carry_mod
+    f = lambda x: (3 * x + 1) % M
+    lut, _ = ks.sk.generate_lookup_table(f)
+    lut_id = eng.upload_lut(lut)
+    # keyswitch + zero-mask PBS: bit-exact
+    rng = np.random.default_rng(8)
+    cts = rng.integers(0, 2**64, size=(5, params.big_size), dtype=np.uint64)
+    assert np.array_equal(eng.keyswitch(cts), np.stack([ks.sk.keyswitch(c) for c in cts]))
+    small = np.zeros((4, params.small_size), dtype=np.uint64)
+    small[:, -1] = np.array([0, 2**64 - 1, 2**63, 0x0123456789ABCDEF], dtype=np.uint64)
+    idx = np.full(4, lut_id, dtype=np.uint32)
+    assert np.array_equal(eng.pbs(small, idx), np.stack([ks.sk.pbs(s, lut) for s in small]))
+    # full KS+PBS: decrypt-exact, phase close to the oracle's f64 path
+    msgs = np.array([0, 1, M // 2, M - 1, 5, 7])
+    enc = ks.ck.encrypt_many(msgs, O.Rng(99, 3))
+    got = eng.apply_lookup_table(enc, np.full(len(msgs), lut_id, dtype=np.uint32))
+    assert np.array_equal(ks.ck.decrypt_many(got), np.array([f(int(m)) for m in msgs]))
+    want = ks.sk.apply_lookup_table_batch(enc, lut)
+    dist = torus_distance(_phases(ks, got), _phases(ks, want))
+    print(f"{params.name}: max phase distance GPU vs oracle-fft = 2^{np.log2(dist.max() + 1):.1f}")
+    assert dist.max() < params.delta / 8
