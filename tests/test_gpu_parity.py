@@ -222,3 +222,25 @@ def test_large_polynomial_sizes(params):
     dist = torus_distance(_phases(ks, got), _phases(ks, want))
     print(f"{params.name}: max phase distance GPU vs oracle-fft = 2^{np.log2(dist.max() + 1):.1f}")
     assert dist.max() < params.delta / 8
+
+
+def test_p44_end_to_end_real_parameters():
+    """PARAM_MESSAGE_4_CARRY_4_KS_PBS exactly as the reference defines it (shortint/parameters/mod.rs:
+    1063-1077: n = 996, N = 32768, 2 PBS levels): client keygen (CPU, ~40 s on 16 threads), KS+PBS on
+    the GPU, decrypt == f(message).  The oracle is not involved (its keygen would double the time);
+    the large-N kernels are checked against it on the toy-n shapes above."""
+    import fhestr
+    P = fhestr.Params(996, 1, 32768, 15, 2, 3, 7, 16, 16, 6.767666038309478e-08, 2.168404344971009e-19,
+                      "PARAM_MESSAGE_4_CARRY_4_KS_PBS")
+    ck = fhestr.ClientKey(P, 0x5EED0005)
+    bsk, ksk = ck.gen_server_keys(16)
+    eng = fhestr.Engine(P, 0)
+    eng.load_keys(bsk, ksk)
+    del bsk, ksk
+    M = 256
+    f = lambda x: (x * x + 3) % M
+    lut_id, _ = eng.generate_lookup_table(f)
+    msgs = np.array([0, 1, 2, 15, 16, 100, 200, 255, 128, 127, 64, 33])
+    out = eng.apply_lookup_table(ck.encrypt(msgs), np.full(len(msgs), lut_id, dtype=np.uint32))
+    assert ck.decrypt(out).tolist() == [f(int(m)) for m in msgs]
+    eng.close()

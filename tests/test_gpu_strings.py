@@ -207,3 +207,22 @@ def test_sharded_runner_gpu_backend_single_rank(toy_k1):
         eng.set_stream(None)
         if created:
             dist.destroy_process_group()
+
+
+def test_string_ops_with_4_bit_blocks_large_n():
+    """BASELINE.json config 5 geometry: msg_mod = carry_mod = 16 (one char = 2 blocks) on the
+    N = 32768 polynomial size of PARAM_MESSAGE_4_CARRY_4 (toy LWE dimension so keys are quick)."""
+    import fhestr
+    ks = keyset(O.TOY_N32768)
+    eng = gpu_engine(ks)
+    ops = fhestr.FheStringOps(eng)
+    assert ops.bpc == 2
+    s = b" Hello, World "
+    es = ks.ck.encrypt_many(fhestr.string_to_blocks(eng.params, s, 16))
+    dec = lambda ct: fhestr.blocks_to_string(eng.params, ks.ck.decrypt_many(np.asarray(ct).reshape(-1, ks.params.big_size)))
+    assert dec(ops.to_lower(es)) == s.lower()
+    assert dec(ops.to_upper(es)) == s.upper()
+    assert dec(ops.replace(es, b"l", b"L")) == s.replace(b"l", b"L")
+    assert dec(ops.strip(es)) == s.strip()
+    assert ks.ck.decrypt_many(ops.contains(es, b"World")[None, :])[0] == 1
+    assert ks.ck.decrypt_many(ops.eq(es, es)[None, :])[0] == 1
