@@ -102,8 +102,15 @@ static const std::vector<BrVariant>& variants() {
         // toy shapes used by the fast tests
         make_variant<8, 2, 2, 2>(), make_variant<7, 2, 3, 1>(),
         make_wide_variant<8, 2, 2, 2>(), make_wide_variant<7, 2, 3, 1>(),
-        // polynomial sizes beyond the LDS: PARAM_MESSAGE_3_CARRY_3 (N = 8192) and PARAM_MESSAGE_4_CARRY_4 (N = 32768)
-        make_large_variant<13, 2, 2>(), make_large_variant<15, 2, 2>(),
+        // the remaining *_KS_PBS shapes of shortint/parameters/mod.rs
+        make_variant<8, 2, 6, 1>(),                                  // N = 256, k = 5  (1_CARRY_0)
+        make_variant<9, 2, 3, 2>(),                                  // N = 512, k = 2, 2 levels (2_CARRY_0)
+        make_wide_variant<12, 2, 2, 1>(), make_wide_variant<12, 2, 2, 2>(),   // N = 4096 (2_CARRY_3 ..., 1_CARRY_4)
+        // polynomial sizes beyond the LDS: four-step FFT through an HBM workspace
+        make_large_variant<13, 2, 1>(), make_large_variant<13, 2, 2>(),       // N = 8192  (5_CARRY_1 ..., 3_CARRY_3 ...)
+        make_large_variant<14, 2, 2>(),                                       // N = 16384 (3_CARRY_4 ...)
+        make_large_variant<15, 2, 2>(),                                       // N = 32768 (4_CARRY_4 ...)
+        make_large_variant<14, 2, 3>(), make_large_variant<15, 2, 3>(),       // 3 levels of base 2^11 (1_CARRY_6, 3_CARRY_5 ...)
     };
     return v;
 }
@@ -124,8 +131,8 @@ static const BrVariant* find_variant(const fhe_params_t& p, int selector) {
 // ---- Engine -----------------------------------------------------------------------------------
 int Engine::create(const fhe_params_t& p, int device, Engine** out) {
     if ((p.N & (p.N - 1)) || p.N < 128) return fail("polynomial size must be a power of two >= 128");
-    if (p.pbs_base_log * p.pbs_level > 31 || p.pbs_base_log < 1)
-        return fail("pbs_base_log * pbs_level must be in [1, 31]");
+    if (p.pbs_base_log < 1 || p.pbs_base_log > 31 || p.pbs_base_log * p.pbs_level > (p.pbs_level >= 3 ? 62u : 31u))
+        return fail("unsupported PBS decomposition (base_log * level must be <= 31, or <= 62 with >= 3 levels)");
     if (p.ks_base_log < 1 || p.ks_base_log > 7 || p.ks_base_log * p.ks_level > 62)
         return fail("unsupported keyswitch decomposition");
     if (p.msg_mod * p.carry_mod == 0 || (p.N % (p.msg_mod * p.carry_mod)) != 0)

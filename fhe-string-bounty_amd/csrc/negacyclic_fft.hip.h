@@ -166,6 +166,8 @@ FHE_SWZ(10, 4, 6, 9, 24, 3, 2, 1, 14, 4, 21, 0, 0, 0, 0, 0, 0, 0)
 FHE_SWZ(9, 3, 5, 2, 4, 26, 8, 4, 29, 16, 1, 0, 0, 0, 0, 0, 0, 0)
 FHE_SWZ(9, 2, 5, 24, 2, 6, 17, 11, 16, 2, 2, 0, 0, 0, 0, 0, 0, 0)
 FHE_SWZ(8, 2, 10, 1, 25, 4, 12, 3, 16, 8, 0, 0, 0, 0, 0, 0, 0, 0)
+FHE_SWZ(7, 2, 2, 4, 10, 25, 1, 5, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+FHE_SWZ(11, 2, 18, 28, 9, 10, 1, 4, 16, 4, 8, 2, 9, 0, 0, 0, 0, 0)
 #undef FHE_SWZ
 
 template <class PL>

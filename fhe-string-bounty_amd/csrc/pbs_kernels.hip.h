@@ -52,6 +52,20 @@ __device__ __forceinline__ int32_t decomp_next_digit(uint32_t& state, uint32_t b
     state += carry;
     return (int32_t)(res - (carry << base_log));
 }
+// 64-bit state variants for base_log * level > 31 (e.g. base 2^11 x 3 levels)
+__device__ __forceinline__ uint64_t decomp_init_state64(uint64_t x, uint32_t bL) {
+    const uint64_t t = x >> (63 - bL);
+    return ((t + 1ull) >> 1) & ((1ull << bL) - 1ull);
+}
+__device__ __forceinline__ int32_t decomp_next_digit64(uint64_t& state, uint32_t base_log) {
+    const uint64_t mask = (1ull << base_log) - 1ull;
+    uint64_t res = state & mask;
+    state >>= base_log;
+    uint64_t carry = ((res - 1ull) | state) & res;
+    carry >>= base_log - 1;
+    state += carry;
+    return (int32_t)(uint32_t)(res - (carry << base_log));
+}
 // Single-level fast path (L == 1): the state IS the only digit's residue, so
 // digit = res - (res > B/2 ? B : 0)  -- the same value iter.rs:120-127 yields when state >> b == 0
 // (carry = bit b-1 of ((res-1) & res) = [res > B/2]).

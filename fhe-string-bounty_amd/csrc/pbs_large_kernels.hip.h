@@ -16,6 +16,8 @@
 // The spectrum order is whatever the two in-place transforms leave; the Fourier key is converted
 // with the same code (bsk_convert_large_kernel), so the pointwise product needs no reordering.
 #pragma once
+#include <type_traits>
+
 #include "pbs_kernels.hip.h"
 
 namespace fhe {
@@ -218,7 +220,9 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
             const uint64_t* ap = acc + (size_t)p * N;
             for (int b0 = 0; b0 < P2; b0 += CFG::SUBS_A) {
                 const int b = b0 + subA;
-                uint32_t st_lo[R], st_hi[R];
+                // decomposition state: 32 bits suffice while base_log * level <= 31 (L <= 2 here)
+                using state_t = typename std::conditional<(L >= 3), uint64_t, uint32_t>::type;
+                state_t st_lo[R], st_hi[R];
 #pragma unroll
                 for (int m = 0; m < R; m++) {
 #pragma unroll
@@ -228,7 +232,9 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
                         const bool neg = (j < rem) != odd;
                         uint64_t v = ap[src];
                         v = neg ? (0 - v) : v;
-                        const uint32_t st = decomp_init_state(v - ap[j], bL);
+                        state_t st;
+                        if constexpr (L >= 3) st = decomp_init_state64(v - ap[j], bL);
+                        else st = decomp_init_state(v - ap[j], bL);
                         if (h == 0) st_lo[m] = st; else st_hi[m] = st;
                     }
                 }
@@ -239,8 +245,13 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
                     for (int m = 0; m < R; m++) {
                         const int j = (tauA + CFG::TA * m) * P2 + b;
                         cplx z;
-                        z.re = (double)decomp_next_digit(st_lo[m], args.base_log);
-                        z.im = (double)decomp_next_digit(st_hi[m], args.base_log);
+                        if constexpr (L >= 3) {
+                            z.re = (double)decomp_next_digit64(st_lo[m], args.base_log);
+                            z.im = (double)decomp_next_digit64(st_hi[m], args.base_log);
+                        } else {
+                            z.re = (double)decomp_next_digit(st_lo[m], args.base_log);
+                            z.im = (double)decomp_next_digit(st_hi[m], args.base_log);
+                        }
                         x[m] = cmul(z, unit_root((double)j / (double)(2 * N)));
                     }
                     column_forward_store<CFG>(x, fca, areA, aimA, tauA, b, tmp + (size_t)(it * K1 + p) * P);

@@ -99,6 +99,19 @@ TOY_K2 = Params(12, 2, 128, 12, 1, 3, 5, 2, 2, 1e-12, 1e-15, "TOY_K2_N128_L1")
 # large-polynomial shapes (PARAM_MESSAGE_3_CARRY_3 / PARAM_MESSAGE_4_CARRY_4 geometry, tiny n)
 TOY_N8192 = Params(8, 1, 8192, 15, 2, 3, 6, 8, 8, 1e-13, 1e-17, "TOY_N8192_L2")
 TOY_N32768 = Params(4, 1, 32768, 15, 2, 3, 7, 16, 16, 1e-13, 1e-17, "TOY_N32768_L2")
+# remaining (N, k, level, base) shapes of the reference's *_KS_PBS parameter table, tiny n
+TOY_SHAPES = [
+    Params(6, 5, 256, 15, 1, 5, 2, 2, 1, 1e-12, 1e-15, "TOY_N256_K5"),        # 1_CARRY_0
+    Params(6, 2, 512, 8, 2, 4, 3, 4, 1, 1e-12, 1e-15, "TOY_N512_K2_L2"),      # 2_CARRY_0
+    Params(6, 3, 512, 18, 1, 4, 3, 2, 2, 1e-12, 1e-15, "TOY_N512_K3"),        # 1_CARRY_1
+    Params(6, 2, 1024, 23, 1, 4, 3, 4, 2, 1e-12, 1e-16, "TOY_N1024_K2"),      # 2_CARRY_1
+    Params(6, 1, 4096, 22, 1, 3, 6, 4, 8, 1e-13, 1e-17, "TOY_N4096_L1"),      # 2_CARRY_3
+    Params(6, 1, 4096, 15, 2, 3, 6, 2, 16, 1e-13, 1e-17, "TOY_N4096_L2"),     # 1_CARRY_4
+    Params(6, 1, 8192, 22, 1, 3, 6, 32, 2, 1e-13, 1e-17, "TOY_N8192_L1"),     # 5_CARRY_1
+    Params(4, 1, 16384, 15, 2, 3, 6, 8, 16, 1e-13, 1e-17, "TOY_N16384_L2"),   # 3_CARRY_4
+    Params(4, 1, 16384, 11, 3, 3, 6, 2, 64, 1e-13, 1e-17, "TOY_N16384_L3"),   # 1_CARRY_6
+    Params(3, 1, 32768, 11, 3, 3, 7, 8, 32, 1e-13, 1e-17, "TOY_N32768_L3"),   # 3_CARRY_5
+]
 
 _u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")

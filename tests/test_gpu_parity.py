@@ -244,3 +244,26 @@ def test_p44_end_to_end_real_parameters():
     out = eng.apply_lookup_table(ck.encrypt(msgs), np.full(len(msgs), lut_id, dtype=np.uint32))
     assert ck.decrypt(out).tolist() == [f(int(m)) for m in msgs]
     eng.close()
+
+
+@pytest.mark.parametrize("params", O.TOY_SHAPES, ids=lambda p: p.name)
+def test_every_reference_parameter_shape(params):
+    """One toy-n instance of every (N, k, level) shape in shortint/parameters/mod.rs that the engine
+    instantiates: keyswitch + zero-mask PBS bit-exact, KS+PBS decrypt-exact."""
+    ks = keyset(params)
+    eng = gpu_engine(ks)
+    M = params.msg_mod * params.carry_mod
+    f = lambda x: (M - 1 - x)
+    lut, _ = ks.sk.generate_lookup_table(f)
+    lut_id = eng.upload_lut(lut)
+    rng = np.random.default_rng(11)
+    cts = rng.integers(0, 2**64, size=(3, params.big_size), dtype=np.uint64)
+    assert np.array_equal(eng.keyswitch(cts), np.stack([ks.sk.keyswitch(c) for c in cts]))
+    small = np.zeros((3, params.small_size), dtype=np.uint64)
+    small[:, -1] = np.array([0, 2**64 - 1, 0x0123456789ABCDEF], dtype=np.uint64)
+    idx = np.full(3, lut_id, dtype=np.uint32)
+    assert np.array_equal(eng.pbs(small, idx), np.stack([ks.sk.pbs(s, lut) for s in small]))
+    msgs = np.array(sorted({0, 1, M // 2, M - 1}))
+    enc = ks.ck.encrypt_many(msgs, O.Rng(7, 7))
+    got = eng.apply_lookup_table(enc, np.full(len(msgs), lut_id, dtype=np.uint32))
+    assert np.array_equal(ks.ck.decrypt_many(got), np.array([f(int(m)) for m in msgs]))
