@@ -187,7 +187,10 @@ def main():
     #      one RCCL all-gather per level; single GPU = same code with world 1 ----
     string_ops = None
     if not args.no_strings:
-        string_ops = bench_strings(fhestr, eng, ck, P, rank, world, local_rank)
+        try:
+            string_ops = bench_strings(fhestr, eng, ck, P, rank, world, local_rank)
+        except Exception as e:   # never let the secondary section take the headline number down
+            string_ops = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         total_pbs = B * world * args.steps

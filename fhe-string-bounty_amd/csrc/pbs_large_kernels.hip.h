@@ -36,8 +36,13 @@ struct BrLargeCfg {
     static constexpr int THREADS = 512;
     static constexpr int SUBS_A = THREADS / TA, SUBS_B = THREADS / TB;   // transforms in flight
     static constexpr int SLOTS_A = 2 * P1 + 4, SLOTS_B = 2 * P2 + 4;     // LDS slots per transform
-    static constexpr size_t LDS_BYTES =
+    static constexpr size_t LDS_PLANES =
         (size_t)(SUBS_A * SLOTS_A > SUBS_B * SLOTS_B ? SUBS_A * SLOTS_A : SUBS_B * SLOTS_B) * 8;
+    // unit roots e^{2 pi i e / 2N}, e < 2N, as a product of two table entries (low / high bits of e):
+    // replaces sincospi in the twist and inter-step twiddles (it was > half of the kernel's VALU work)
+    static constexpr int ROOT_BITS = LOGN + 1, ROOT_LO = ROOT_BITS / 2, ROOT_HI = ROOT_BITS - ROOT_LO;
+    static constexpr size_t LDS_ROOTS = ((size_t)(1 << ROOT_LO) + (size_t)(1 << ROOT_HI)) * 16;
+    static constexpr size_t LDS_BYTES = LDS_PLANES + LDS_ROOTS;
     // per-LWE workspace in HBM (bytes): acc | tmp[L*K1][P] c64 | tmp2[K1][P] c64
     static constexpr size_t WS_ACC = (size_t)K1 * N * 8;
     static constexpr size_t WS_TMP = (size_t)L * K1 * P * 16;
@@ -75,19 +80,47 @@ __device__ __forceinline__ cplx unit_root(double turns) {   // e^{2 pi i turns}
     return w;
 }
 
+// e^{2 pi i e / 2N} from the two LDS tables (e taken mod 2N)
+template <class CFG>
+struct RootTable {
+    const double2* lo;
+    const double2* hi;
+    __device__ __forceinline__ void init(double2* base, int tid, int nthreads) {
+        double2* l = base;
+        double2* h = base + (1 << CFG::ROOT_LO);
+        for (int e = tid; e < (1 << CFG::ROOT_LO); e += nthreads) {
+            const cplx w = unit_root((double)e / (double)(2 * CFG::N));
+            l[e] = make_double2(w.re, w.im);
+        }
+        for (int e = tid; e < (1 << CFG::ROOT_HI); e += nthreads) {
+            const cplx w = unit_root((double)((size_t)e << CFG::ROOT_LO) / (double)(2 * CFG::N));
+            h[e] = make_double2(w.re, w.im);
+        }
+        lo = l; hi = h;
+    }
+    __device__ __forceinline__ cplx get(uint32_t e) const {
+        e &= (2u * CFG::N - 1u);
+        const double2 a = lo[e & ((1u << CFG::ROOT_LO) - 1u)], b = hi[e >> CFG::ROOT_LO];
+        cplx r;
+        r.re = a.x * b.x - a.y * b.y;
+        r.im = a.x * b.y + a.y * b.x;
+        return r;
+    }
+};
+
 // ---- phase helpers -------------------------------------------------------------------------------
 // column transform forward: x[m] holds point (a = tau + TA*m, column b); result slot rho is written to
 // dst[slot_addr * P2 + b] after the inter-step twiddle w_P^{-q1*b} (forward sign convention e^{-2 pi i})
 template <class CFG>
 __device__ __forceinline__ void column_forward_store(cplx* x, const FftConsts<typename CFG::PA>& fc, double* re,
-                                                     double* im, int tau, int b, double2* dst) {
+                                                     double* im, int tau, int b, double2* dst, const RootTable<CFG>& roots) {
     using PA = typename CFG::PA;
     fft_forward<PA>(x, fc, re, im, tau);
 #pragma unroll
     for (int rho = 0; rho < CFG::R; rho++) {
         const int A = slot_addr<PA>(tau, rho);
         const int q1 = freq_of_addr<PA>(A);
-        const cplx w = unit_root(-(double)((q1 * b) & (CFG::P - 1)) / (double)CFG::P);
+        const cplx w = roots.get(0u - 4u * (uint32_t)(q1 * b));     // e^{-2 pi i q1 b / P}, 1/P = 4/(2N)
         const cplx v = cmul(x[rho], w);
         dst[(size_t)A * CFG::P2 + b] = make_double2(v.re, v.im);
     }
@@ -112,6 +145,9 @@ bsk_convert_large_kernel(const uint64_t* __restrict__ bsk_std, double* __restric
     fft_init_consts<PA>(fca, tauA);
     fft_init_consts<PB>(fcb, tauB);
     double2* tmp = workspace + (size_t)blockIdx.x * P;
+    RootTable<CFG> roots;
+    roots.init(reinterpret_cast<double2*>(smem + CFG::LDS_PLANES), tid, CFG::THREADS);
+    __syncthreads();
     for (uint32_t poly = blockIdx.x; poly < n_polys; poly += gridDim.x) {
         const uint64_t* src = bsk_std + (size_t)poly * N;
         for (int b0 = 0; b0 < P2; b0 += CFG::SUBS_A) {
@@ -123,10 +159,10 @@ bsk_convert_large_kernel(const uint64_t* __restrict__ bsk_std, double* __restric
                 cplx z;   // forward_as_torus (fft/mod.rs:197-218) with the inverse's 1/P folded in
                 z.re = i64_to_f64(src[j]) * (5.421010862427522e-20 / P);
                 z.im = i64_to_f64(src[j + P]) * (5.421010862427522e-20 / P);
-                x[m] = cmul(z, unit_root((double)j / (double)(2 * N)));   // twisty e^{i pi j / N}
+                x[m] = cmul(z, roots.get((uint32_t)j));   // twisty e^{i pi j / N}
             }
             column_forward_store<CFG>(x, fca, lds + (size_t)subA * CFG::SLOTS_A, lds + (size_t)subA * CFG::SLOTS_A + P1 + 2,
-                                      tauA, b, tmp);
+                                      tauA, b, tmp, roots);
         }
         __syncthreads();
         double2* out = reinterpret_cast<double2*>(fbsk) + (size_t)poly * P;
@@ -185,6 +221,8 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
     FftConsts<PB> fcb;
     fft_init_consts<PA>(fca, tauA);
     fft_init_consts<PB>(fcb, tauB);
+    RootTable<CFG> roots;
+    roots.init(reinterpret_cast<double2*>(smem + CFG::LDS_PLANES), tid, NT);
 
     // acc <- LUT * X^{-ms(body)}
     {
@@ -252,9 +290,9 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
                             z.re = (double)decomp_next_digit(st_lo[m], args.base_log);
                             z.im = (double)decomp_next_digit(st_hi[m], args.base_log);
                         }
-                        x[m] = cmul(z, unit_root((double)j / (double)(2 * N)));
+                        x[m] = cmul(z, roots.get((uint32_t)j));
                     }
-                    column_forward_store<CFG>(x, fca, areA, aimA, tauA, b, tmp + (size_t)(it * K1 + p) * P);
+                    column_forward_store<CFG>(x, fca, areA, aimA, tauA, b, tmp + (size_t)(it * K1 + p) * P, roots);
                 }
             }
         }
@@ -303,7 +341,7 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
 #pragma unroll
                 for (int m = 0; m < R; m++) {
                     const int b = tauB + CFG::TB * m;
-                    const cplx w = unit_root((double)((q1 * b) & (P - 1)) / (double)P);   // conj of the forward twiddle
+                    const cplx w = roots.get(4u * (uint32_t)(q1 * b));   // conj of the forward twiddle
                     const cplx v = cmul(outf[col][m], w);
                     drow[b] = make_double2(v.re, v.im);
                 }
@@ -327,7 +365,7 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
 #pragma unroll
                 for (int m = 0; m < R; m++) {
                     const int j = (tauA + CFG::TA * m) * P2 + b;
-                    const cplx t = cmul_conj(x[m], unit_root((double)j / (double)(2 * N)));
+                    const cplx t = cmul_conj(x[m], roots.get((uint32_t)j));
                     ap[j] += from_torus(t.re);
                     ap[j + P] += from_torus(t.im);
                 }
