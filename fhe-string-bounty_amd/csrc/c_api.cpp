@@ -240,7 +240,7 @@ int fhe_plan_lut(fhe_plan* p, const uint64_t* table, uint32_t* lut) {
     PLAN_BUILDING(p); CHECK_PTR(table); CHECK_PTR(lut);
     std::vector<uint64_t> t(table, table + p->c->total_modulus());
     *lut = p->c->lut(t);
-    if (p->c->failed()) return fail(p->c->error());
+    if (p->c->failed()) return fail(p->c->take_error());
     return 0;
     API_END
 }
@@ -252,7 +252,7 @@ int fhe_plan_lin(fhe_plan* p, const uint32_t* nodes, const int32_t* coeffs, uint
     std::vector<fhe::Term> terms;
     for (uint32_t i = 0; i < n_terms; i++) terms.push_back({nodes[i], coeffs[i]});
     *node = p->c->lin(terms, constant);
-    if (p->c->failed()) return fail(p->c->error());
+    if (p->c->failed()) return fail(p->c->take_error());
     return 0;
     API_END
 }
@@ -261,7 +261,7 @@ int fhe_plan_pbs(fhe_plan* p, uint32_t src, uint32_t lut, uint32_t* node) {
     API_BEGIN
     PLAN_BUILDING(p); CHECK_PTR(node);
     *node = p->c->pbs(src, lut);
-    if (p->c->failed()) return fail(p->c->error());
+    if (p->c->failed()) return fail(p->c->take_error());
     return 0;
     API_END
 }

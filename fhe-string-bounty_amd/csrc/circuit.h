@@ -76,6 +76,7 @@ public:
     const Node& node(uint32_t id) const { return nodes_[id]; }
     bool failed() const { return !error_.empty(); }
     const std::string& error() const { return error_; }
+    std::string take_error() { std::string e; e.swap(error_); return e; }   // report once, then keep building
 
     // ---- finalise + query ----
     int finalize(uint32_t world);                 // assigns levels' pool regions (padded per rank)
