@@ -120,6 +120,14 @@ int fhe_pbs_batch(fhe_engine* eng, const uint64_t* in, const uint32_t* lut_idx, 
     API_END
 }
 
+int fhe_pbs_ks_batch(fhe_engine* eng, const uint64_t* in, const uint32_t* lut_idx, uint64_t* out,
+                     uint32_t count) {
+    API_BEGIN
+    CHECK_PTR(eng); CHECK_PTR(in); CHECK_PTR(out);
+    return eng->impl->pbs_ks_host(in, lut_idx, out, count);
+    API_END
+}
+
 int fhe_ks_pbs_batch(fhe_engine* eng, const uint64_t* in, const uint32_t* lut_idx, uint64_t* out,
                      uint32_t count) {
     API_BEGIN

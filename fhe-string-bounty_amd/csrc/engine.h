@@ -66,6 +66,7 @@ struct Engine {
     int ks_pbs_host(const uint64_t* in, const uint32_t* lut_idx, uint64_t* out, uint32_t count);
     int keyswitch_host(const uint64_t* in, uint64_t* out_small, uint32_t count);
     int pbs_host(const uint64_t* in_small, const uint32_t* lut_idx, uint64_t* out, uint32_t count);
+    int pbs_ks_host(const uint64_t* in_small, const uint32_t* lut_idx, uint64_t* out_small, uint32_t count);
     int lincomb_dev(const uint64_t* d_pool, const uint32_t* d_off, const uint32_t* d_src,
                     const int32_t* d_coeff, const uint64_t* d_cst, uint64_t* d_out, uint32_t jobs);
     int lincomb_host(const uint64_t* pool, uint32_t pool_count, const uint32_t* off, const uint32_t* src,

@@ -423,6 +423,30 @@ int Engine::pbs_host(const uint64_t* in_small, const uint32_t* lut_idx, uint64_t
     return 0;
 }
 
+// Small-key order (programmable_bootstrap_keyswitch_assign, shortint/server_key/mod.rs:859-932):
+// ciphertexts live under the small LWE key; bootstrap first, then keyswitch back.
+int Engine::pbs_ks_host(const uint64_t* in_small, const uint32_t* lut_idx, uint64_t* out_small, uint32_t count) {
+    if (use()) return 1;
+    if (count == 0) return 0;
+    if (check_lut_idx(lut_idx, count)) return 1;
+    if (ensure_batch(count)) return 1;
+    const size_t small = (size_t)p.n + 1;
+    uint64_t* d_small2 = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_small2, count * small * 8));
+    HIP_TRY(hipMemcpyAsync(d_small, in_small, count * small * 8, hipMemcpyHostToDevice, stream));
+    if (lut_idx) HIP_TRY(hipMemcpyAsync(d_idx, lut_idx, (size_t)count * 4, hipMemcpyHostToDevice, stream));
+    int rc = launch_blind_rotate(d_small, lut_idx ? d_idx : nullptr, d_out, count);
+    if (!rc) rc = launch_keyswitch(d_out, d_small2, count);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(out_small, d_small2, count * small * 8, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) rc = fail(std::string("pbs_ks copy back: ") + hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(d_small2);
+    return rc;
+}
+
 int Engine::lincomb_dev(const uint64_t* d_pool_, const uint32_t* d_off, const uint32_t* d_src,
                         const int32_t* d_coeff, const uint64_t* d_cst, uint64_t* d_o, uint32_t jobs) {
     if (jobs == 0) return 0;

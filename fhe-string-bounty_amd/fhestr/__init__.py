@@ -93,7 +93,7 @@ EXPORTS = [
     "fhe_last_error", "fhe_engine_create", "fhe_engine_destroy", "fhe_engine_params",
     "fhe_engine_load_keys", "fhe_engine_stream", "fhe_engine_synchronize", "fhe_engine_set_variant",
     "fhe_lut_generate", "fhe_lut_upload", "fhe_lut_download", "fhe_lut_count",
-    "fhe_keyswitch_batch", "fhe_pbs_batch", "fhe_ks_pbs_batch", "fhe_ks_pbs_batch_dev",
+    "fhe_keyswitch_batch", "fhe_pbs_batch", "fhe_ks_pbs_batch", "fhe_ks_pbs_batch_dev", "fhe_pbs_ks_batch",
     "fhe_lwe_lincomb_batch", "fhe_last_kernel_ms", "fhe_kernel_times",
     "fhe_params_ksk_len", "fhe_params_bsk_len", "fhe_client_key_create", "fhe_client_key_destroy",
     "fhe_client_encrypt", "fhe_client_decrypt", "fhe_client_gen_server_keys", "fhe_client_secret_keys",
@@ -151,6 +151,7 @@ def lib() -> C.CDLL:
     sig("fhe_pbs_batch", vp, vp, vp, vp, u32)
     sig("fhe_ks_pbs_batch", vp, vp, vp, vp, u32)
     sig("fhe_ks_pbs_batch_dev", vp, vp, vp, vp, u32)
+    sig("fhe_pbs_ks_batch", vp, vp, vp, vp, u32)
     sig("fhe_lwe_lincomb_batch", vp, vp, u32, vp, vp, vp, vp, vp, u32)
     sig("fhe_last_kernel_ms", vp, C.POINTER(C.c_float))
     sig("fhe_kernel_times", vp, C.POINTER(C.c_double), C.POINTER(u32), i32)
@@ -316,6 +317,15 @@ class Engine:
         out = np.zeros_like(cts)
         idx, ip = self._idx(lut_idx, cts.shape[0])
         _check(lib().fhe_ks_pbs_batch(self._h, _ptr(cts), ip, _ptr(out), cts.shape[0]))
+        return out
+
+    def apply_lookup_table_small_key(self, cts_small, lut_idx=None) -> np.ndarray:
+        """PBS -> KS order on small-key ciphertexts (shortint/server_key/mod.rs:859-932)."""
+        p = self.params
+        cts_small = _u64(cts_small).reshape(-1, p.small_size)
+        out = np.zeros_like(cts_small)
+        idx, ip = self._idx(lut_idx, cts_small.shape[0])
+        _check(lib().fhe_pbs_ks_batch(self._h, _ptr(cts_small), ip, _ptr(out), cts_small.shape[0]))
         return out
 
     def apply_lookup_table_dev(self, d_in: int, d_lut_idx: int | None, d_out: int, count: int):

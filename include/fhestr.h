@@ -88,6 +88,10 @@ int fhe_pbs_batch(fhe_engine *eng, const uint64_t *lwe_small_in, const uint32_t 
  * (shortint/server_key/mod.rs:457-476,783-857), batched, host buffers. */
 int fhe_ks_pbs_batch(fhe_engine *eng, const uint64_t *lwe_big_in, const uint32_t *lut_idx,
                      uint64_t *lwe_big_out, uint32_t count);
+/* Small-key order: programmable_bootstrap_keyswitch_assign (shortint/server_key/mod.rs:859-932, the
+ * *_PBS_KS parameter sets): small LWEs in, bootstrap, keyswitch, small LWEs out. */
+int fhe_pbs_ks_batch(fhe_engine *eng, const uint64_t *lwe_small_in, const uint32_t *lut_idx,
+                     uint64_t *lwe_small_out, uint32_t count);
 /* Same with everything resident in HBM; asynchronous on the engine stream. */
 int fhe_ks_pbs_batch_dev(fhe_engine *eng, const uint64_t *d_lwe_big_in, const uint32_t *d_lut_idx,
                          uint64_t *d_lwe_big_out, uint32_t count);

@@ -267,3 +267,24 @@ def test_every_reference_parameter_shape(params):
     enc = ks.ck.encrypt_many(msgs, O.Rng(7, 7))
     got = eng.apply_lookup_table(enc, np.full(len(msgs), lut_id, dtype=np.uint32))
     assert np.array_equal(ks.ck.decrypt_many(got), np.array([f(int(m)) for m in msgs]))
+
+
+def test_pbs_then_keyswitch_small_key_order(toy_k1):
+    """*_PBS_KS parameter sets keep ciphertexts under the small key: bootstrap, then keyswitch
+    (shortint/server_key/mod.rs:859-932).  Checked against the oracle's two stages."""
+    import ctypes as C
+    ks, params = toy_k1, toy_k1.params
+    eng = gpu_engine(ks)
+    M = params.msg_mod * params.carry_mod
+    f = lambda x: (x + 5) % M
+    lut, _ = ks.sk.generate_lookup_table(f)
+    lut_id = eng.upload_lut(lut)
+    rng = O.Rng(321, 1)
+    small = np.zeros((M, params.small_size), dtype=np.uint64)
+    for m in range(M):   # encrypt under the small key with the small-key noise
+        O.lib().orc_lwe_encrypt(ks.ck.small_sk, params.n, m * params.delta, params.lwe_std, rng.ptr, small[m])
+    got = eng.apply_lookup_table_small_key(small, np.full(M, lut_id, dtype=np.uint32))
+    dec = [int(O.lib().orc_decode(C.byref(params.c()), ks.ck.decrypt_small_plaintext(c))) for c in got]
+    assert dec == [f(m) for m in range(M)]
+    want = np.stack([ks.sk.keyswitch(ks.sk.pbs(s, lut)) for s in small])
+    assert [int(O.lib().orc_decode(C.byref(params.c()), ks.ck.decrypt_small_plaintext(c))) for c in want] == dec
