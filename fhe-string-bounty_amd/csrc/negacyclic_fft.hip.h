@@ -336,111 +336,117 @@ __device__ __forceinline__ void fft_inverse(cplx* x, const FftConsts<PL>& c, dou
 // can overlap one polynomial's LDS round trip with another one's butterflies.  `re0` is the first
 // polynomial's real plane; planes of polynomial p start at re0 + p*poly_stride, imaginary plane at
 // +im_off.
+// helpers: move the R points of one polynomial between registers and its LDS planes in the layout of pass s
+template <class PL>
+__device__ __forceinline__ void pass_load(cplx* x, int s, const double* re, const double* im, int tau) {
+    const int rr = 1 << PL::log_radix(s);
+    const int groups = PL::R / rr;
+#pragma unroll
+    for (int gi = 0; gi < groups; gi++) {
+        const int base = lds_slot<PL>(pass_addr<PL>(s, tau, gi, 0));
+#pragma unroll
+        for (int m = 0; m < rr; m++) {
+            const int a = base ^ lds_slot<PL>(pass_addr<PL>(s, 0, 0, m));
+            x[gi * rr + m].re = re[a];
+            x[gi * rr + m].im = im[a];
+        }
+    }
+}
+template <class PL>
+__device__ __forceinline__ void pass_store(const cplx* x, int s, double* re, double* im, int tau) {
+    const int rr = 1 << PL::log_radix(s);
+    const int groups = PL::R / rr;
+#pragma unroll
+    for (int gi = 0; gi < groups; gi++) {
+        const int base = lds_slot<PL>(pass_addr<PL>(s, tau, gi, 0));
+#pragma unroll
+        for (int m = 0; m < rr; m++) {
+            const int a = base ^ lds_slot<PL>(pass_addr<PL>(s, 0, 0, m));
+            re[a] = x[gi * rr + m].re;
+            im[a] = x[gi * rr + m].im;
+        }
+    }
+}
+template <class PL, bool INV>
+__device__ __forceinline__ void pass_compute(cplx* x, int s, const FftConsts<PL>& c) {
+    constexpr int R = PL::R;
+    const int lr = PL::log_radix(s);
+    const int rr = 1 << lr;
+    if (INV && s < PL::NTW) {
+#pragma unroll
+        for (int q = 1; q < R; q++) x[q] = cmul_conj(x[q], c.tw[s][q]);
+    }
+    if (lr == PL::LOGR) {
+        small_dft<R, INV>(x);
+    } else {
+#pragma unroll
+        for (int gi = 0; gi < R / rr; gi++) small_dft<(1 << PL::LOGLAST), INV>(x + gi * rr);
+    }
+    if (!INV && s < PL::NTW) {
+#pragma unroll
+        for (int q = 1; q < R; q++) x[q] = cmul(x[q], c.tw[s][q]);
+    }
+}
+__device__ __forceinline__ bool pass_sync_is_wave_local(int log_S_next) { return (1 << log_S_next) <= 64; }
+
+// Forward transform of NPOLY polynomials carried by the same threads.  Exchanges that need a
+// workgroup barrier are done for all polynomials at once; wave-local exchanges are software
+// pipelined: polynomial p's store + the next pass's load are issued before polynomial p+1's
+// butterflies, so the LDS round trip of one stream hides behind the VALU work of the other.
 template <class PL, int NPOLY>
 __device__ __forceinline__ void fft_forward_multi(cplx (*x)[PL::R], const FftConsts<PL>& c, double* re0,
                                                   int poly_stride, int im_off, int tau) {
-    constexpr int R = PL::R;
+    bool loaded = true;   // pass 0 operands are already in registers
 #pragma unroll
     for (int s = 0; s < PL::NP; s++) {
-        const int lr = PL::log_radix(s);
-        const int rr = 1 << lr;
-        const int groups = R / rr;
-        if (s > 0) {
-            exchange_sync<PL>(s);
+        const bool last = s + 1 == PL::NP;
+        const bool local_next = !last && pass_sync_is_wave_local(PL::log_S(s + 1));
+        if (!loaded) {
 #pragma unroll
-            for (int gi = 0; gi < groups; gi++) {
-                const int base = lds_slot<PL>(pass_addr<PL>(s, tau, gi, 0));
-#pragma unroll
-                for (int p = 0; p < NPOLY; p++)
-#pragma unroll
-                    for (int m = 0; m < rr; m++) {
-                        const int a = base ^ lds_slot<PL>(pass_addr<PL>(s, 0, 0, m));
-                        x[p][gi * rr + m].re = re0[p * poly_stride + a];
-                        x[p][gi * rr + m].im = re0[p * poly_stride + im_off + a];
-                    }
-            }
+            for (int p = 0; p < NPOLY; p++) pass_load<PL>(x[p], s, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
         }
 #pragma unroll
         for (int p = 0; p < NPOLY; p++) {
-            if (lr == PL::LOGR) {
-                small_dft<R, false>(x[p]);
-            } else {
-#pragma unroll
-                for (int gi = 0; gi < groups; gi++) small_dft<(1 << PL::LOGLAST), false>(x[p] + gi * rr);
-            }
-            if (s < PL::NTW) {
-#pragma unroll
-                for (int q = 1; q < R; q++) x[p][q] = cmul(x[p][q], c.tw[s][q]);
+            pass_compute<PL, false>(x[p], s, c);
+            if (!last) {
+                pass_store<PL>(x[p], s, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+                if (local_next) {   // in-order LDS execution of this wave: the loads see the stores above
+                    exchange_sync<PL>(s + 1);
+                    pass_load<PL>(x[p], s + 1, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+                }
             }
         }
-        if (s + 1 < PL::NP) {
-#pragma unroll
-            for (int gi = 0; gi < groups; gi++) {
-                const int base = lds_slot<PL>(pass_addr<PL>(s, tau, gi, 0));
-#pragma unroll
-                for (int p = 0; p < NPOLY; p++)
-#pragma unroll
-                    for (int m = 0; m < rr; m++) {
-                        const int a = base ^ lds_slot<PL>(pass_addr<PL>(s, 0, 0, m));
-                        re0[p * poly_stride + a] = x[p][gi * rr + m].re;
-                        re0[p * poly_stride + im_off + a] = x[p][gi * rr + m].im;
-                    }
-            }
-        }
+        if (!last && !local_next) exchange_sync<PL>(s + 1);
+        loaded = local_next;
     }
 }
 
 template <class PL, int NPOLY>
 __device__ __forceinline__ void fft_inverse_multi(cplx (*x)[PL::R], const FftConsts<PL>& c, double* re0,
                                                   int poly_stride, int im_off, int tau) {
-    constexpr int R = PL::R;
+    bool loaded = true;   // last-pass operands are in registers
 #pragma unroll
     for (int s = PL::NP - 1; s >= 0; s--) {
-        const int lr = PL::log_radix(s);
-        const int rr = 1 << lr;
-        const int groups = R / rr;
-        if (s + 1 < PL::NP) {
-            exchange_sync<PL>(s + 1);
+        // exchange between pass s and pass s-1 is the one exchange_sync(s) describes
+        const bool first = s == 0;
+        const bool local_next = !first && pass_sync_is_wave_local(PL::log_S(s));
+        if (!loaded) {
 #pragma unroll
-            for (int gi = 0; gi < groups; gi++) {
-                const int base = lds_slot<PL>(pass_addr<PL>(s, tau, gi, 0));
-#pragma unroll
-                for (int p = 0; p < NPOLY; p++)
-#pragma unroll
-                    for (int m = 0; m < rr; m++) {
-                        const int a = base ^ lds_slot<PL>(pass_addr<PL>(s, 0, 0, m));
-                        x[p][gi * rr + m].re = re0[p * poly_stride + a];
-                        x[p][gi * rr + m].im = re0[p * poly_stride + im_off + a];
-                    }
-            }
+            for (int p = 0; p < NPOLY; p++) pass_load<PL>(x[p], s, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
         }
 #pragma unroll
         for (int p = 0; p < NPOLY; p++) {
-            if (s < PL::NTW) {
-#pragma unroll
-                for (int q = 1; q < R; q++) x[p][q] = cmul_conj(x[p][q], c.tw[s][q]);
-            }
-            if (lr == PL::LOGR) {
-                small_dft<R, true>(x[p]);
-            } else {
-#pragma unroll
-                for (int gi = 0; gi < groups; gi++) small_dft<(1 << PL::LOGLAST), true>(x[p] + gi * rr);
+            pass_compute<PL, true>(x[p], s, c);
+            if (!first) {
+                pass_store<PL>(x[p], s, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+                if (local_next) {
+                    exchange_sync<PL>(s);
+                    pass_load<PL>(x[p], s - 1, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+                }
             }
         }
-        if (s > 0) {
-#pragma unroll
-            for (int gi = 0; gi < groups; gi++) {
-                const int base = lds_slot<PL>(pass_addr<PL>(s, tau, gi, 0));
-#pragma unroll
-                for (int p = 0; p < NPOLY; p++)
-#pragma unroll
-                    for (int m = 0; m < rr; m++) {
-                        const int a = base ^ lds_slot<PL>(pass_addr<PL>(s, 0, 0, m));
-                        re0[p * poly_stride + a] = x[p][gi * rr + m].re;
-                        re0[p * poly_stride + im_off + a] = x[p][gi * rr + m].im;
-                    }
-            }
-        }
+        if (!first && !local_next) exchange_sync<PL>(s);
+        loaded = local_next;
     }
 }
 

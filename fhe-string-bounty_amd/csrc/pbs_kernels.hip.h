@@ -232,9 +232,11 @@ blind_rotate_kernel(BlindRotateArgs args) {
         {
             const double2* bk = bk0 + (size_t)(L - 1) * K1 * K1 * P;
 #pragma unroll
-            for (int row = 0; row < K1; row++)
+            for (int r = 0; r < K1; r++) {
+                const int row = (g + r) % K1;       // r = 0 is this group's own row: branch-free below
 #pragma unroll
-                for (int rho = 0; rho < R; rho++) bpre[row][rho] = bk[((size_t)row * K1 + g) * P + rho * T + tau];
+                for (int rho = 0; rho < R; rho++) bpre[r][rho] = bk[((size_t)row * K1 + g) * P + rho * T + tau];
+            }
         }
 
         // ct1 = acc * X^d - acc  (polynomial_algorithms.rs:463-489), then decomposition state
@@ -282,20 +284,21 @@ blind_rotate_kernel(BlindRotateArgs args) {
             // outf[col = g] (+)= sum_row FBSK[i][lvl][row][g] * F[row]   (ggsw.rs:616-697)
             const double2* bk = bk0 + (size_t)lvl_idx * K1 * K1 * P;
 #pragma unroll
-            for (int row = 0; row < K1; row++) {
+            for (int r = 0; r < K1; r++) {
+                const int row = (g + r) % K1;                    // own row first (spectrum still in registers)
                 const double* fre = lds_f + (size_t)row * CFG::GROUP_SLOTS;
                 const double* fim = fre + CFG::PLANE;
 #pragma unroll
                 for (int rho = 0; rho < R; rho++) {
-                    const double2 bv = it == 0 ? bpre[row][rho] : bk[((size_t)row * K1 + g) * P + rho * T + tau];
+                    const double2 bv = it == 0 ? bpre[r][rho] : bk[((size_t)row * K1 + g) * P + rho * T + tau];
                     cplx f;
-                    if (row == g) {
-                        f = x[rho];                              // own spectrum is still in registers
+                    if (r == 0) {
+                        f = x[rho];
                     } else {
                         f.re = fre[rho * T + tau];
                         f.im = fim[rho * T + tau];
                     }
-                    if (it == 0 && row == 0) {
+                    if (it == 0 && r == 0) {
                         outf[rho].re = bv.x * f.re - bv.y * f.im;
                         outf[rho].im = bv.x * f.im + bv.y * f.re;
                     } else {
