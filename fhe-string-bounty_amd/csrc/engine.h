@@ -33,7 +33,8 @@ struct Engine {
     int cu_count = 256;
 
     // resident keys / tables
-    uint64_t* d_ksk = nullptr;
+    uint64_t* d_ksk = nullptr;       // reference layout (kept only when the byte-plane path is disabled)
+    uint32_t* d_ksk_packed = nullptr; // [rows/4][8][n+1] byte planes for keyswitch_dot4_kernel
     double* d_fbsk = nullptr;
     uint64_t* d_luts = nullptr;
     size_t luts_cap = 0;

@@ -169,7 +169,7 @@ Engine::~Engine() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     auto rel = [](void* ptr) { if (ptr) (void)hipFree(ptr); };
-    rel(d_ksk); rel(d_fbsk); rel(d_luts); rel(d_in); rel(d_small); rel(d_out); rel(d_idx);
+    rel(d_ksk); rel(d_ksk_packed); rel(d_fbsk); rel(d_luts); rel(d_in); rel(d_small); rel(d_out); rel(d_idx);
     rel(d_pool); rel(d_meta); rel(d_ws);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ring) if (e) (void)hipEventDestroy(e);
@@ -230,6 +230,18 @@ int Engine::load_keys(const uint64_t* bsk_std, const uint64_t* ksk) {
     if (d_fbsk) { HIP_TRY(hipFree(d_fbsk)); d_fbsk = nullptr; }
     HIP_TRY(hipMalloc((void**)&d_ksk, ksk_len * 8));
     HIP_TRY(hipMemcpyAsync(d_ksk, ksk, ksk_len * 8, hipMemcpyHostToDevice, stream));
+    if (d_ksk_packed) { HIP_TRY(hipFree(d_ksk_packed)); d_ksk_packed = nullptr; }
+    static const bool use_dot4 = !(getenv("FHESTR_KS_MAD64") && atoi(getenv("FHESTR_KS_MAD64")));
+    if (use_dot4) {   // repack into byte planes once; the 64-bit layout is then released
+        const uint32_t rows = p.k * p.N * p.ks_level, osz = p.n + 1;
+        HIP_TRY(hipMalloc((void**)&d_ksk_packed, (size_t)(rows / 4) * 8 * osz * 4));
+        hipLaunchKernelGGL(ksk_pack_kernel, dim3((osz + 255) / 256, rows / 4), dim3(256), 0, stream,
+                           d_ksk, d_ksk_packed, rows, osz);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipFree(d_ksk));
+        d_ksk = nullptr;
+    }
     uint64_t* d_std = nullptr;
     HIP_TRY(hipMalloc((void**)&d_std, bsk_len * 8));
     HIP_TRY(hipMalloc((void**)&d_fbsk, bsk_len * 8));   // N u64 -> N/2 c64: same byte count
@@ -321,9 +333,16 @@ int Engine::ensure_batch(uint32_t count) {
 }
 
 int Engine::launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t count) {
-    if (!d_ksk) return fail("keys not loaded");
+    if (!d_ksk && !d_ksk_packed) return fail("keys not loaded");
     const uint32_t in_dim = p.k * p.N, out_size = p.n + 1;
     HIP_TRY(hipMemsetAsync(d_sm, 0, (size_t)count * out_size * 8, stream));
+    if (d_ksk_packed) {
+        KeyswitchPackedArgs pa{d_big, d_ksk_packed, d_sm, in_dim, out_size, p.ks_base_log, p.ks_level, count};
+        dim3 pgrid((out_size + KS_COLS - 1) / KS_COLS, (count + KSD_S - 1) / KSD_S, (in_dim + KS_IC - 1) / KS_IC);
+        hipLaunchKernelGGL(keyswitch_dot4_kernel, pgrid, dim3(KS_COLS), (size_t)KS_IC * p.ks_level * KSD_S, stream, pa);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     KeyswitchArgs a{d_big, d_ksk, d_sm, in_dim, out_size, p.ks_base_log, p.ks_level, count};
     dim3 grid((out_size + KS_COLS - 1) / KS_COLS, (count + KS_S - 1) / KS_S, (in_dim + KS_IC - 1) / KS_IC);
     const size_t lds = (size_t)KS_IC * p.ks_level * KS_S;

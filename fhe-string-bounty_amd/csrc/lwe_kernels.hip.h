@@ -105,6 +105,120 @@ __global__ void __launch_bounds__(KS_COLS) keyswitch_kernel(KeyswitchArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Byte-plane variant.  The multiply-accumulate above issues two v_mad_u64_u32 per (sample, KSK
+// element) and is bound by that instruction.  Exact reformulation with 8-bit dot products:
+//   KSK[r][col] = sum_t byte_t(r, col) << 8t,      digit' in [0, 2^b] fits a byte as well, so
+//   sum_r KSK[r][col] * d'[r] = sum_t ( sum_r byte_t(r, col) * d'[r] ) << 8t   (mod 2^64)
+// and the inner sums over 4 consecutive rows are one v_dot4_u32_u8 each (u32 accumulators cannot
+// overflow: 255 * 128 * rows-per-tile < 2^32).  Two dot4 per element instead of two 64-bit mads;
+// every step is integer ring arithmetic, so the result stays bit-identical to the reference loop.
+// The key is repacked once at load time:  packed[r/4][t][col] = bytes t of rows r..r+3 (u32).
+__global__ void __launch_bounds__(256) ksk_pack_kernel(const uint64_t* __restrict__ ksk, uint32_t* __restrict__ packed,
+                                                       uint32_t rows, uint32_t out_size) {
+    const uint32_t col = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t r4 = blockIdx.y;
+    if (col >= out_size) return;
+    uint64_t v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[q] = (r4 * 4 + q) < rows ? ksk[(size_t)(r4 * 4 + q) * out_size + col] : 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) w |= (uint32_t)((v[q] >> (8 * t)) & 0xff) << (8 * q);
+        packed[((size_t)r4 * 8 + t) * out_size + col] = w;
+    }
+}
+
+constexpr int KSD_S = 8;      // samples per tile of the byte-plane kernel (64 u32 accumulators per thread)
+
+struct KeyswitchPackedArgs {
+    const uint64_t* lwe_in;    // [B][in_dim+1]
+    const uint32_t* packed;    // [in_dim*level/4][8][out_size]
+    uint64_t* lwe_out;         // [B][out_size], zero-filled before launch
+    uint32_t in_dim, out_size, base_log, level, batch;
+};
+
+__global__ void __launch_bounds__(KS_COLS, 2) keyswitch_dot4_kernel(KeyswitchPackedArgs a) {
+    extern __shared__ __align__(16) unsigned char ks_smem[];   // [rows/4][KSD_S] u32: 4 biased digits each
+    uint32_t* dig = reinterpret_cast<uint32_t*>(ks_smem);
+    const uint32_t col = blockIdx.x * KS_COLS + threadIdx.x;
+    const uint32_t b0 = blockIdx.y * KSD_S;
+    const uint32_t i0 = blockIdx.z * KS_IC;
+    const uint32_t L = a.level, bl = a.base_log;
+    const uint32_t half = 1u << (bl - 1);
+    const uint32_t rows = KS_IC * L;                            // multiple of 4 (KS_IC is)
+
+    for (uint32_t e = threadIdx.x; e < (uint32_t)(KS_IC * KSD_S); e += KS_COLS) {
+        const uint32_t il = e / KSD_S, s = e % KSD_S;
+        const uint32_t i = i0 + il, b = b0 + s;
+        uint64_t x = 0;
+        if (i < a.in_dim && b < a.batch) x = a.lwe_in[(size_t)b * (a.in_dim + 1) + i];
+        const uint32_t rep = bl * L;
+        uint64_t t = x >> (63 - rep);
+        uint64_t state = ((t + 1) >> 1) & ((1ull << rep) - 1);
+        const uint64_t mask = (1ull << bl) - 1;
+        unsigned char* bytes = ks_smem;
+        for (uint32_t lv = 0; lv < L; lv++) {
+            uint64_t res = state & mask;
+            state >>= bl;
+            uint64_t carry = ((res - 1ull) | state) & res;
+            carry >>= bl - 1;
+            state += carry;
+            const int32_t digit = (int32_t)(uint32_t)res - (int32_t)((uint32_t)carry << bl);
+            const uint32_t r = il * L + lv;
+            bytes[((size_t)(r >> 2) * KSD_S + s) * 4 + (r & 3)] = (unsigned char)(digit + (int32_t)half);
+        }
+    }
+    __syncthreads();
+
+    uint32_t acc[KSD_S][8];
+#pragma unroll
+    for (int s = 0; s < KSD_S; s++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) acc[s][t] = 0;
+    uint32_t sumk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool col_ok = col < a.out_size;
+    const uint32_t ccol = col_ok ? col : 0;
+    const uint32_t* kp = a.packed + ((size_t)(i0 * L) / 4) * 8 * a.out_size + ccol;
+    for (uint32_t r4 = 0; r4 < rows / 4; r4++) {
+        uint32_t kb[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) kb[t] = kp[((size_t)r4 * 8 + t) * a.out_size];
+        uint32_t dw[KSD_S];
+#pragma unroll
+        for (int q = 0; q < KSD_S / 4; q++) {
+            const uint4 dq = *reinterpret_cast<const uint4*>(dig + (size_t)r4 * KSD_S + q * 4);
+            dw[4 * q + 0] = dq.x; dw[4 * q + 1] = dq.y; dw[4 * q + 2] = dq.z; dw[4 * q + 3] = dq.w;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            sumk[t] = __builtin_amdgcn_udot4(kb[t], 0x01010101u, sumk[t], false);
+#pragma unroll
+            for (int s = 0; s < KSD_S; s++) acc[s][t] = __builtin_amdgcn_udot4(kb[t], dw[s], acc[s][t], false);
+        }
+    }
+    if (!col_ok) return;
+    uint64_t corr = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) corr += (uint64_t)sumk[t] << (8 * t);
+    corr *= (uint64_t)half;
+#pragma unroll
+    for (int s = 0; s < KSD_S; s++) {
+        const uint32_t b = b0 + s;
+        if (b >= a.batch) break;
+        uint64_t p = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) p += (uint64_t)acc[s][t] << (8 * t);
+        uint64_t v = corr - p;
+        if (blockIdx.z == 0 && col == a.out_size - 1)
+            v += a.lwe_in[(size_t)b * (a.in_dim + 1) + a.in_dim];
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.lwe_out + (size_t)b * a.out_size + col),
+                  (unsigned long long)v);
+    }
+}
+
 // out[j][:] = sum_{t in [off[j], off[j+1])} coeff[t] * pool[src[t]][:]  ;  out[j][body] += cst[j]
 struct LincombArgs {
     const uint64_t* pool;      // [*][size]
