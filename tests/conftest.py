@@ -78,12 +78,3 @@ def torus_distance(a, b):
     d = (np.asarray(a, dtype=np.uint64) - np.asarray(b, dtype=np.uint64)).astype(np.int64)
     return np.abs(d).astype(np.float64)
 
-
-def pytest_runtest_teardown(item, nextitem):
-    if os.environ.get("FHESTR_DEBUG_DEVCOUNT"):
-        import torch
-        try:
-            n = torch._C._cuda_getDeviceCount()
-        except Exception as e:  # pragma: no cover
-            n = f"ERR {e}"
-        sys.stderr.write(f"\n[devcount] after {item.name}: {n}\n")
