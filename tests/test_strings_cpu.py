@@ -151,3 +151,19 @@ def test_sharded_runner_world2_gloo(toy_k1):
         p.join(120)
         assert p.exitcode == 0
     assert dict(ret) == {0: single, 1: single} and single == 1
+
+
+def test_config1_eq_8_chars_p22_cpu_reference_path(p22):
+    """BASELINE.json configs[0] / SURVEY.md 8(d) config 1: FheString::eq on two 8-char ASCII strings,
+    PARAM_MESSAGE_2_CARRY_2, CPU path only (the planner's levels executed by the oracle), keys from
+    seed 0x5EED0001; "fhe-str!" vs itself -> 1, vs "fhe-str?" -> 0; 32 block PBS + 3 + 1 reduce."""
+    import fhestr
+    P = to_fhestr_params(O.PARAM_MESSAGE_2_CARRY_2_KS_PBS)
+    plan = fhestr.Plan.string_op(None, "eq", 8, 8, params=P)
+    info = plan.info()
+    assert (info["n_pbs"], info["n_levels"]) == (32 + 3 + 1, 3)
+    enc = lambda s: p22.ck.encrypt_many(fhestr.string_to_blocks(P, s, 8))
+    a = enc(b"fhe-str!")
+    for other, want in ((b"fhe-str!", 1), (b"fhe-str?", 0)):
+        out = run_with_oracle(plan, np.concatenate([a, enc(other)]), p22.sk)
+        assert p22.ck.decrypt_many(out)[0] == want
