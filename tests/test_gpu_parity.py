@@ -288,3 +288,31 @@ def test_pbs_then_keyswitch_small_key_order(toy_k1):
     assert dec == [f(m) for m in range(M)]
     want = np.stack([ks.sk.keyswitch(ks.sk.pbs(s, lut)) for s in small])
     assert [int(O.lib().orc_decode(C.byref(params.c()), ks.ck.decrypt_small_plaintext(c))) for c in want] == dec
+
+
+def test_p22_output_noise_matches_oracle(p22):
+    """Statistical parity: the error of the bootstrapped phase (phase - delta*f(m)) has the same
+    spread on the GPU as in the oracle's f64 and exact-integer paths, and sits far below delta/2."""
+    eng = gpu_engine(p22)
+    params = p22.params
+    lut, _ = p22.sk.generate_lookup_table(lambda x: x)
+    lut_id = eng.upload_lut(lut)
+    rng = np.random.default_rng(42)
+    msgs = rng.integers(0, 16, size=192)
+    cts = p22.ck.encrypt_many(msgs, O.Rng(4242, 1))
+    got = eng.apply_lookup_table(cts, np.full(len(msgs), lut_id, dtype=np.uint32))
+
+    def errors(outs, ms):
+        ph = _phases(p22, outs).astype(np.uint64)
+        with np.errstate(over="ignore"):
+            e = (ph - ms.astype(np.uint64) * np.uint64(params.delta)).astype(np.int64)
+        return e.astype(np.float64)
+
+    e_gpu = errors(got, msgs)
+    e_fft = errors(p22.sk.apply_lookup_table_batch(cts[:64], lut), msgs[:64])
+    assert np.abs(e_gpu).max() < params.delta / 8
+    s_gpu, s_fft = e_gpu.std(), e_fft.std()
+    print(f"PBS output noise std: GPU 2^{np.log2(s_gpu):.2f} (n=192), oracle-fft 2^{np.log2(s_fft):.2f} (n=64), "
+          f"delta/2 = 2^{np.log2(params.delta / 2):.0f}")
+    assert 0.6 < s_gpu / s_fft < 1.6
+    assert abs(e_gpu.mean()) < 4 * s_gpu / np.sqrt(len(e_gpu)) + 1.0   # unbiased
