@@ -437,6 +437,8 @@ STR_BINARY(starts_with)
 STR_BINARY(ends_with)
 STR_BINARY(contains)
 STR_BINARY(find)
+STR_BINARY(rfind)
+STR_BINARY(eq_ignore_case)
 
 int fhe_str_replace(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, const uint64_t* from_to,
                     uint32_t pat_cap, uint64_t* out) {
@@ -458,6 +460,20 @@ int fhe_str_trim_end(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, uint64_
 }
 int fhe_str_strip(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, uint64_t* out) {
     return str_op(eng, "strip", a, a_cap, nullptr, 0, nullptr, 0, out);
+}
+int fhe_str_len(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, uint64_t* out) {
+    return str_op(eng, "len", a, a_cap, nullptr, 0, nullptr, 0, out);
+}
+int fhe_str_is_empty(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, uint64_t* out) {
+    return str_op(eng, "is_empty", a, a_cap, nullptr, 0, nullptr, 0, out);
+}
+int fhe_str_strip_prefix_clear(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, const uint8_t* pat,
+                               uint32_t pat_len, uint64_t* out) {
+    return str_op(eng, "strip_prefix_clear", a, a_cap, nullptr, 0, pat, pat_len, out);
+}
+int fhe_str_strip_suffix_clear(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, const uint8_t* pat,
+                               uint32_t pat_len, uint64_t* out) {
+    return str_op(eng, "strip_suffix_clear", a, a_cap, nullptr, 0, pat, pat_len, out);
 }
 int fhe_str_to_upper(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, uint64_t* out) {
     return str_op(eng, "to_upper", a, a_cap, nullptr, 0, nullptr, 0, out);

@@ -293,7 +293,11 @@ public:
         return out;
     }
     // outputs: found bit, then n_digits base-M digits (little endian) of the first matching offset
-    void find_from_matches(const std::vector<uint32_t>& match, uint32_t n_digits, std::vector<uint32_t>& out) {
+    // from_end: select the LAST matching offset instead of the first (rfind)
+    void find_from_matches(const std::vector<uint32_t>& match_in, uint32_t n_digits, std::vector<uint32_t>& out,
+                           bool from_end = false) {
+        std::vector<uint32_t> match(match_in);
+        if (from_end) std::reverse(match.begin(), match.end());
         std::vector<uint32_t> pre = prefix_or(match);
         const uint32_t found = pre.back();
         // first[o] = match[o] AND NOT pre[o-1]  ==  (match[o] + 2*pre[o-1]) == 1
@@ -301,6 +305,7 @@ public:
         std::vector<uint32_t> first(match.size());
         for (size_t o = 0; o < match.size(); o++)
             first[o] = o == 0 ? match[0] : c.pbs(c.lin({{match[o], 1}, {pre[o - 1], 2}}), first_lut);
+        if (from_end) std::reverse(first.begin(), first.end());   // one-hot vector back on the original offsets
         out.push_back(found);
         const uint32_t F = T - 1;
         for (uint32_t d = 0; d < n_digits; d++) {
@@ -363,7 +368,7 @@ public:
             const uint32_t lc = c.pbs(c.lin(lo_terms), lo_lut);
             const uint32_t delta = c.pbs(c.lin({{hc, 4}, {lc, 1}}), comb);
             for (uint32_t k = 0; k < bpc; k++) {
-                if (k == blk) out.push_back(c.lin({{b[k], 1}, {delta, to_lower ? 1 : -1}}));
+                if (k == blk) out.push_back(c.lin({{b[k], 1}, {delta, to_lower ? 1 : -1}}, 0, (int64_t)M - 1));   // letters never carry
                 else out.push_back(b[k]);
             }
         }
@@ -501,6 +506,64 @@ public:
             if (std::memcmp(p, p + m - b, b) == 0) return true;
         return false;
     }
+    // ---- length, emptiness, case-insensitive equality, prefix / suffix stripping ----
+    uint32_t is_empty(const Str& s) { return char_is_zero(s.ch[0]); }
+    // len = offset of the first null char (cap when there is none): found bit is always 1
+    void len(const Str& s, uint32_t n_digits, std::vector<uint32_t>& out) {
+        std::vector<uint32_t> z;
+        for (uint32_t i = 0; i < s.cap; i++) z.push_back(char_is_zero(s.ch[i]));
+        z.push_back(c.trivial(1));
+        std::vector<uint32_t> tmp;
+        find_from_matches(z, n_digits, tmp);
+        out.assign(tmp.begin() + 1, tmp.end());
+    }
+    Str case_folded(const Str& s) {
+        std::vector<uint32_t> blocks;
+        change_case(s, true, blocks);
+        Str out;
+        out.cap = s.cap;
+        out.ch.resize(s.cap);
+        for (uint32_t i = 0; i < s.cap; i++) out.ch[i].assign(blocks.begin() + (size_t)i * bpc, blocks.begin() + (size_t)(i + 1) * bpc);
+        return out;
+    }
+    // sel ? a : b on blocks (if_then_else without the final message_extract, integer/.../cmux.rs:194-248)
+    uint32_t select_block(uint32_t sel, uint32_t a, uint32_t b) {
+        return c.lin({{gate_block(a, sel, true), 1}, {gate_block(b, sel, false), 1}}, 0, M - 1);
+    }
+    // strip_prefix (clear pattern of length m): if s starts with it, drop it (shift left by m)
+    Str strip_prefix_clear(const Str& s, const uint8_t* pat, uint32_t m, uint32_t* stripped_bit) {
+        const uint32_t sel = starts_with_clear(s, pat, m);
+        *stripped_bit = sel;
+        if (m == 0 || m > s.cap) return s;
+        Str out;
+        out.cap = s.cap;
+        out.ch.resize(s.cap);
+        for (uint32_t i = 0; i < s.cap; i++)
+            for (uint32_t k = 0; k < bpc; k++)
+                out.ch[i].push_back(i + m < s.cap ? select_block(sel, s.ch[i + m][k], s.ch[i][k]) : gate_block(s.ch[i][k], sel, false));
+        return out;
+    }
+    // strip_suffix (clear pattern): zero every char from the matching offset on
+    Str strip_suffix_clear(const Str& s, const uint8_t* pat, uint32_t m, uint32_t* stripped_bit) {
+        if (m > s.cap) { *stripped_bit = c.trivial(0); return s; }
+        if (m == 0) { *stripped_bit = c.trivial(1); return s; }
+        std::vector<uint32_t> mt = window_matches_clear(s, pat, m, s.cap - m + 1), cand;
+        for (uint32_t o = 0; o + m <= s.cap; o++) {
+            if (o + m == s.cap) { cand.push_back(mt[o]); continue; }
+            const uint32_t l = c.lut_fn([](uint64_t x) { return (uint64_t)(x == 2); });
+            cand.push_back(c.pbs(c.lin({{mt[o], 1}, {char_is_zero(s.ch[o + m]), 1}}), l));
+        }
+        std::vector<uint32_t> cut = prefix_or(cand);            // cut[i] = suffix starts at or before i
+        *stripped_bit = cut.back();
+        Str out;
+        out.cap = s.cap;
+        out.ch.resize(s.cap);
+        for (uint32_t i = 0; i < s.cap; i++)
+            for (uint32_t k = 0; k < bpc; k++)
+                out.ch[i].push_back(i < cut.size() ? gate_block(s.ch[i][k], cut[i], false)
+                                                   : gate_block(s.ch[i][k], cut.back(), false));
+        return out;
+    }
     void emit(const Str& s) {
         for (auto& blocks : s.ch)
             for (uint32_t b : blocks) c.output(b);
@@ -520,7 +583,7 @@ int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t 
     Str a = s.input_string(a_cap);
     Str b;
     const bool unary = base == "to_upper" || base == "to_lower" || base == "trim_start" || base == "trim_end" ||
-                       base == "strip" || base == "trim";
+                       base == "strip" || base == "trim" || base == "len" || base == "is_empty";
     const bool is_replace = base == "replace";
     if (!is_clear && !unary) {
         if (b_cap == 0) return fail("pattern capacity must be > 0");
@@ -537,7 +600,29 @@ int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t 
         c.output(is_clear ? s.ends_with_clear(a, clear, clear_len) : s.ends_with(a, b));
     } else if (base == "contains") {
         c.output(is_clear ? s.contains_clear(a, clear, clear_len) : s.contains(a, b));
-    } else if (base == "find") {
+    } else if (base == "eq_ignore_case") {
+        if (is_clear) {
+            std::vector<uint8_t> lower(clear, clear + clear_len);
+            for (auto& ch : lower) if (ch >= 'A' && ch <= 'Z') ch += 32;
+            c.output(s.eq_clear(s.case_folded(a), lower.data(), clear_len, true));
+        } else {
+            c.output(s.eq(s.case_folded(a), s.case_folded(b), true));
+        }
+    } else if (base == "is_empty") {
+        c.output(s.is_empty(a));
+    } else if (base == "len") {
+        std::vector<uint32_t> outs;
+        s.len(a, n_digits, outs);
+        for (uint32_t o : outs) c.output(o);
+    } else if (base == "strip_prefix" || base == "strip_suffix") {
+        if (!is_clear) return fail(base + " is implemented for clear patterns only");
+        uint32_t bit = 0;
+        Str r = base == "strip_prefix" ? s.strip_prefix_clear(a, clear, clear_len, &bit)
+                                       : s.strip_suffix_clear(a, clear, clear_len, &bit);
+        c.output(bit);          // first output: 1 iff the pattern was stripped
+        s.emit(r);
+    } else if (base == "find" || base == "rfind") {
+        const bool from_end = base == "rfind";
         std::vector<uint32_t> match;
         if (is_clear) {
             if (clear_len > a_cap) match.assign(1, c.trivial(0));
@@ -545,9 +630,23 @@ int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t 
             else match = s.window_matches_clear(a, clear, clear_len, a_cap - clear_len + 1);
         } else {
             match = s.window_matches(a, b, a_cap, true);
+            if (from_end) {
+                // an (all-padding) pattern also "matches" past the end of the string: only offsets
+                // o <= len(s) count, i.e. o == 0 or s[o-1] != 0
+                const uint32_t both = c.lut_fn([](uint64_t x) { return (uint64_t)(x == 1); });
+                for (uint32_t o = 1; o < match.size(); o++)
+                    match[o] = c.pbs(c.lin({{match[o], 1}, {s.char_is_zero(a.ch[o - 1]), 2}}, 0, 3), both);
+            }
         }
         std::vector<uint32_t> outs;
-        s.find_from_matches(match, n_digits, outs);
+        if (from_end && is_clear && clear_len == 0) {       // "".rfind in s == len(s)
+            outs.push_back(c.trivial(1));
+            std::vector<uint32_t> digits;
+            s.len(a, n_digits, digits);
+            outs.insert(outs.end(), digits.begin(), digits.end());
+        } else {
+            s.find_from_matches(match, n_digits, outs, from_end);
+        }
         for (uint32_t o : outs) c.output(o);
     } else if (base == "to_upper" || base == "to_lower") {
         std::vector<uint32_t> outs;

@@ -103,7 +103,8 @@ EXPORTS = [
     "fhe_str_to_upper", "fhe_str_to_lower", "fhe_plan_create_offline", "fhe_str_plan_create_offline",
     "fhe_str_trim_start", "fhe_str_trim_end", "fhe_str_strip", "fhe_str_replace", "fhe_str_replace_clear",
     "fhe_plan_lut_count", "fhe_plan_export_lut", "fhe_engine_set_stream", "fhe_engine_reset_stream",
-] + [f"fhe_str_{n}{s}" for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find")
+    "fhe_str_len", "fhe_str_is_empty", "fhe_str_strip_prefix_clear", "fhe_str_strip_suffix_clear",
+] + [f"fhe_str_{n}{s}" for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find", "rfind", "eq_ignore_case")
      for s in ("", "_clear")]
 
 
@@ -182,7 +183,11 @@ def lib() -> C.CDLL:
     sig("fhe_plan_run_level_slice_dev", vp, vp, u32, u32, u32)
     sig("fhe_plan_gather_outputs_dev", vp, vp, vp)
     sig("fhe_str_plan_create", vp, C.c_char_p, u32, u32, vp, u32, u32, C.POINTER(vp))
-    for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find"):
+    sig("fhe_str_len", vp, vp, u32, vp)
+    sig("fhe_str_is_empty", vp, vp, u32, vp)
+    sig("fhe_str_strip_prefix_clear", vp, vp, u32, vp, u32, vp)
+    sig("fhe_str_strip_suffix_clear", vp, vp, u32, vp, u32, vp)
+    for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find", "rfind", "eq_ignore_case"):
         sig(f"fhe_str_{n}", vp, vp, u32, vp, u32, vp)
         sig(f"fhe_str_{n}_clear", vp, vp, u32, vp, u32, vp)
     for n in ("trim_start", "trim_end", "strip"):
@@ -578,7 +583,7 @@ class FheStringOps:
         n_dig = 0
         while (self.engine.params.msg_mod ** n_dig) < a_cap + 1:
             n_dig += 1
-        n_out = 1 + n_dig if op == "find" else 1
+        n_out = 1 + n_dig if op in ("find", "rfind") else 1
         out = np.zeros((n_out, self.engine.params.big_size), dtype=np.uint64)
         if isinstance(b, (bytes, bytearray)):
             buf = (C.c_uint8 * max(1, len(b)))(*b)
@@ -594,6 +599,36 @@ class FheStringOps:
     def ends_with(self, a, b): return self._binary("ends_with", a, b)[0]
     def contains(self, a, b): return self._binary("contains", a, b)[0]
     def find(self, a, b): return self._binary("find", a, b)
+    def rfind(self, a, b): return self._binary("rfind", a, b)
+    def eq_ignore_case(self, a, b): return self._binary("eq_ignore_case", a, b)[0]
+
+    def _n_digits(self, cap):
+        n = 0
+        while (self.engine.params.msg_mod ** n) < cap + 1:
+            n += 1
+        return n
+
+    def len(self, a):
+        a, a_cap = self._cap(a)
+        out = np.zeros((self._n_digits(a_cap), self.engine.params.big_size), dtype=np.uint64)
+        _check(lib().fhe_str_len(self.engine.handle, _ptr(a), a_cap, _ptr(out)))
+        return out
+
+    def is_empty(self, a):
+        a, a_cap = self._cap(a)
+        out = np.zeros((1, self.engine.params.big_size), dtype=np.uint64)
+        _check(lib().fhe_str_is_empty(self.engine.handle, _ptr(a), a_cap, _ptr(out)))
+        return out[0]
+
+    def _strip_affix(self, op, a, pat: bytes):
+        a, a_cap = self._cap(a)
+        out = np.zeros((1 + a.shape[0], self.engine.params.big_size), dtype=np.uint64)
+        buf = (C.c_uint8 * max(1, len(pat)))(*pat)
+        _check(getattr(lib(), f"fhe_str_{op}_clear")(self.engine.handle, _ptr(a), a_cap, buf, len(pat), _ptr(out)))
+        return out[0], out[1:]
+
+    def strip_prefix(self, a, pat: bytes): return self._strip_affix("strip_prefix", a, pat)
+    def strip_suffix(self, a, pat: bytes): return self._strip_affix("strip_suffix", a, pat)
 
     def _unary(self, op, a):
         a, a_cap = self._cap(a)

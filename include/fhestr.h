@@ -171,6 +171,8 @@ FHE_STR_BINARY_DECL(starts_with)
 FHE_STR_BINARY_DECL(ends_with)
 FHE_STR_BINARY_DECL(contains)
 FHE_STR_BINARY_DECL(find)
+FHE_STR_BINARY_DECL(rfind)            /* last occurrence; same outputs as find */
+FHE_STR_BINARY_DECL(eq_ignore_case)   /* ASCII case folding on both sides, then eq */
 /* whitespace = ASCII 9..13 and 32; results are re-padded with zeros (whole string returned) */
 int fhe_str_trim_start(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
 int fhe_str_trim_end(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
@@ -182,6 +184,15 @@ int fhe_str_replace(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const ui
                     uint32_t pat_cap, uint64_t *out);
 int fhe_str_replace_clear(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const uint8_t *from,
                           const uint8_t *to, uint32_t pat_len, uint64_t *out);
+/* len: ceil(log_msg_mod(cap+1)) little-endian digits; is_empty: one 0/1 block */
+int fhe_str_len(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
+int fhe_str_is_empty(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
+/* strip_prefix / strip_suffix with a clear pattern: out = 1 + cap*blocks LWEs: first a 0/1 block
+ * ("the pattern was there and has been removed"), then the resulting string */
+int fhe_str_strip_prefix_clear(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const uint8_t *pat,
+                               uint32_t pat_len, uint64_t *out);
+int fhe_str_strip_suffix_clear(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const uint8_t *pat,
+                               uint32_t pat_len, uint64_t *out);
 int fhe_str_to_upper(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
 int fhe_str_to_lower(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
 

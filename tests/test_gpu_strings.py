@@ -226,3 +226,26 @@ def test_string_ops_with_4_bit_blocks_large_n():
     assert dec(ops.strip(es)) == s.strip()
     assert ks.ck.decrypt_many(ops.contains(es, b"World")[None, :])[0] == 1
     assert ks.ck.decrypt_many(ops.eq(es, es)[None, :])[0] == 1
+
+
+def test_len_rfind_ignore_case_strip_affix(toy_k1):
+    import fhestr
+    ops = _ops(toy_k1)
+    P = gpu_engine(toy_k1).params
+    s = b"abcabc"
+    es = _enc(toy_k1, s, 8)
+    val = lambda digits: sum(int(d) * 4**i for i, d in enumerate(digits))
+    assert val(_dec(toy_k1, ops.len(es))) == 6
+    assert _dec(toy_k1, ops.is_empty(es))[0] == 0 and _dec(toy_k1, ops.is_empty(_enc(toy_k1, b"", 8)))[0] == 1
+    out = _dec(toy_k1, ops.rfind(es, _enc(toy_k1, b"bc", 4)))
+    assert out[0] == 1 and val(out[1:]) == s.rfind(b"bc")
+    out = _dec(toy_k1, ops.rfind(es, b"zz"))
+    assert out[0] == 0
+    assert _dec(toy_k1, ops.eq_ignore_case(es, _enc(toy_k1, b"ABCabc", 8)))[0] == 1
+    assert _dec(toy_k1, ops.eq_ignore_case(es, b"ABCABD"))[0] == 0
+    bit, rest = ops.strip_prefix(es, b"abc")
+    assert _dec(toy_k1, bit)[0] == 1 and fhestr.blocks_to_string(P, _dec(toy_k1, rest)) == b"abc"
+    bit, rest = ops.strip_suffix(es, b"bc")
+    assert _dec(toy_k1, bit)[0] == 1 and fhestr.blocks_to_string(P, _dec(toy_k1, rest)) == b"abca"
+    bit, rest = ops.strip_suffix(es, b"xx")
+    assert _dec(toy_k1, bit)[0] == 0 and fhestr.blocks_to_string(P, _dec(toy_k1, rest)) == s

@@ -85,6 +85,39 @@ def test_replace_offline_plan_vs_python(toy_k1, s, frm, to):
     assert got == want, ("encrypted", got, want)
 
 
+@pytest.mark.parametrize("s", [b"hello", b"", b"abcdefgh", b"a"])
+def test_len_is_empty_offline_plan_vs_python(toy_k1, s):
+    digits = _run(toy_k1, "len", s, None)
+    assert sum(int(d) * 4**i for i, d in enumerate(digits)) == len(s)
+    assert _run(toy_k1, "is_empty", s, None)[0] == int(len(s) == 0)
+
+
+@pytest.mark.parametrize("s,pat", [(b"abcabc", b"bc"), (b"aaaa", b"aa"), (b"hello", b"zz"), (b"abab", b"")])
+def test_rfind_and_ignore_case_offline_plan_vs_python(toy_k1, s, pat):
+    want = s.rfind(pat)
+    for p in (pat, ("clear", pat)):
+        out = _run(toy_k1, "rfind", s, p)
+        assert out[0] == int(want >= 0)
+        if want >= 0:
+            assert sum(int(d) * 4**i for i, d in enumerate(out[1:])) == want
+    up = s.upper()
+    assert _run(toy_k1, "eq_ignore_case", s, up, pat_cap=8)[0] == 1
+    assert _run(toy_k1, "eq_ignore_case", s, ("clear", up))[0] == 1
+    assert _run(toy_k1, "eq_ignore_case", s, s + b"x", pat_cap=8)[0] == 0
+
+
+@pytest.mark.parametrize("s,pat", [(b"prefix-x", b"pre"), (b"prefix-x", b"-x"), (b"abc", b"abc"), (b"abc", b"x"), (b"aaa", b"a")])
+def test_strip_affix_offline_plan_vs_python(toy_k1, s, pat):
+    import fhestr
+    P = to_fhestr_params(O.TOY_K1)
+    out = _run(toy_k1, "strip_prefix", s, ("clear", pat))
+    assert out[0] == int(s.startswith(pat))
+    assert fhestr.blocks_to_string(P, out[1:]) == (s[len(pat):] if s.startswith(pat) else s)
+    out = _run(toy_k1, "strip_suffix", s, ("clear", pat))
+    assert out[0] == int(s.endswith(pat))
+    assert fhestr.blocks_to_string(P, out[1:]) == (s[: len(s) - len(pat)] if s.endswith(pat) else s)
+
+
 def test_plan_shapes_match_survey_counts():
     # eq enc-enc 256 chars = 1024 + 69 + 5 + 1 PBS, depth 4; enc-clear = 551
     info = _plan("eq", 256, 256).info()
