@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--log2-points", type=int, default=0, help="blind-rotate variant (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strings", action="store_true", help="skip the FheString ms/op section")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep")
     return ap.parse_args()
 
 
@@ -184,6 +185,25 @@ def main():
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
         verified = bool(v.item())
 
+    # ---- batch-size sweep like the reference's throughput bench (benches/core_crypto/pbs_bench.rs:430-549) ----
+    sweep = None
+    if world == 1 and not args.no_sweep:
+        sweep = {}
+        for nb in (1, 16, 64, 128, 256, 512, 1024, 4096):
+            reps_in = (nb + B - 1) // B
+            big_in = d_in.repeat(reps_in, 1)[:nb].contiguous()
+            big_idx = d_idx.repeat(reps_in)[:nb].contiguous()
+            big_out = torch.empty_like(big_in)
+            torch.cuda.synchronize()
+            for it in range(4):
+                if it == 1:
+                    eng.synchronize()
+                    t1 = time.perf_counter()
+                eng.apply_lookup_table_dev(big_in.data_ptr(), big_idx.data_ptr(), big_out.data_ptr(), nb)
+            eng.synchronize()
+            sweep[str(nb)] = round(nb * 3 / (time.perf_counter() - t1), 1)
+        eng.kernel_times(reset=True)
+
     # ---- FheString ms/op (BASELINE.json configs 3 and 4): level batches sharded over the ranks,
     #      one RCCL all-gather per level; single GPU = same code with world 1 ----
     string_ops = None
@@ -227,6 +247,7 @@ def main():
                                     "frac_of_peak": value * pbs_bytes / (world * HBM_PEAK_GBS * 1e9)},
             "verified_decrypt": verified,
             "string_ops": string_ops,
+            "batch_sweep_pbs_per_s": sweep,
         }
         if not args.no_cpu_baseline and world == 1:
             try:

@@ -25,7 +25,7 @@ def build(force: bool = False, arch: str | None = None) -> str:
         cmd = ["make", "-C", _HERE, "-B" if force else "-s"]
         if arch:
             cmd.append(f"ARCH={arch}")
-        subprocess.check_call(cmd)
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL)   # keep the caller's stdout clean (bench.py prints one JSON line)
     return _LIB_PATH
 
 

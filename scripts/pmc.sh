@@ -6,7 +6,7 @@ CTRS=$1; shift
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT/trace -o run -- python3 bench.py --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
+rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT/trace -o run -- python3 bench.py --no-cpu-baseline --no-sweep "$@" > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, sys, glob, collections
 out = sys.argv[1]
