@@ -439,6 +439,10 @@ STR_BINARY(contains)
 STR_BINARY(find)
 STR_BINARY(rfind)
 STR_BINARY(eq_ignore_case)
+STR_BINARY(lt)
+STR_BINARY(le)
+STR_BINARY(gt)
+STR_BINARY(ge)
 
 int fhe_str_replace(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, const uint64_t* from_to,
                     uint32_t pat_cap, uint64_t* out) {

@@ -564,6 +564,52 @@ public:
                                                    : gate_block(s.ch[i][k], cut.back(), false));
         return out;
     }
+    // ---- lexicographic order (the reference's comparator idea: per-block sign, then pairwise
+    //      selection "most significant non-equal wins", integer/server_key/comparator.rs:226-280) ----
+    // sign encoding: 0 = a < b, 1 = equal, 2 = a > b.  Strings compare like big-endian integers of
+    // their (zero padded) bytes, which is exactly bytes.__lt__ on the unpadded strings.
+    uint32_t compare_sign(const Str& a, const Str* b, const uint8_t* clear, uint32_t clear_len) {
+        const uint32_t n = b ? std::max(a.cap, b->cap) : std::max<uint32_t>(a.cap, clear_len);
+        std::vector<uint32_t> signs;   // most significant first
+        const uint32_t mm = M;
+        for (uint32_t i = 0; i < n; i++) {
+            for (int k = (int)bpc - 1; k >= 0; k--) {
+                const bool has_a = i < a.cap;
+                if (b) {
+                    const bool has_b = i < b->cap;
+                    if (has_a && has_b) {   // sign(a - b) from a - b + (M-1) in [0, 2M-2]
+                        const uint32_t l = c.lut_fn([mm](uint64_t x) { return (uint64_t)(x < mm - 1 ? 0 : (x == mm - 1 ? 1 : 2)); });
+                        signs.push_back(c.pbs(c.lin({{a.ch[i][k], 1}, {b->ch[i][k], -1}}, (int64_t)M - 1, 2 * ((int64_t)M - 1)), l));
+                    } else {               // the missing side is a null char
+                        const uint32_t l = c.lut_fn([has_a](uint64_t x) { return (uint64_t)(x == 0 ? 1 : (has_a ? 2 : 0)); });
+                        signs.push_back(c.pbs(has_a ? a.ch[i][k] : b->ch[i][k], l));
+                    }
+                } else {
+                    const uint32_t v = clear_block(i < clear_len ? clear[i] : 0, (uint32_t)k);
+                    if (!has_a) { if (v) signs.push_back(c.trivial(0)); continue; }   // a is null there: a < clear iff clear != 0
+                    const uint32_t l = c.lut_fn([v](uint64_t x) { return (uint64_t)(x < v ? 0 : (x == v ? 1 : 2)); });
+                    signs.push_back(c.pbs(a.ch[i][k], l));
+                }
+            }
+        }
+        if (signs.empty()) return c.trivial(1);
+        const uint32_t pick = c.lut_fn([](uint64_t x) { const uint64_t hi = x / 3, lo = x % 3; return hi != 1 ? (hi > 2 ? (uint64_t)1 : hi) : lo; });
+        while (signs.size() > 1) {
+            std::vector<uint32_t> next;
+            for (size_t i = 0; i + 1 < signs.size(); i += 2)
+                next.push_back(c.pbs(c.lin({{signs[i], 3}, {signs[i + 1], 1}}, 0, 8), pick));
+            if (signs.size() & 1) next.push_back(signs.back());
+            signs.swap(next);
+        }
+        return signs[0];
+    }
+    uint32_t order_bit(uint32_t sign, const std::string& op) {
+        const bool lt = op == "lt", le = op == "le", gt = op == "gt";
+        const uint32_t l = c.lut_fn([lt, le, gt](uint64_t s) {
+            return (uint64_t)(lt ? s == 0 : (le ? s != 2 : (gt ? s == 2 : s != 0)));
+        });
+        return c.pbs(sign, l);
+    }
     void emit(const Str& s) {
         for (auto& blocks : s.ch)
             for (uint32_t b : blocks) c.output(b);
@@ -600,6 +646,8 @@ int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t 
         c.output(is_clear ? s.ends_with_clear(a, clear, clear_len) : s.ends_with(a, b));
     } else if (base == "contains") {
         c.output(is_clear ? s.contains_clear(a, clear, clear_len) : s.contains(a, b));
+    } else if (base == "lt" || base == "le" || base == "gt" || base == "ge") {
+        c.output(s.order_bit(s.compare_sign(a, is_clear ? nullptr : &b, clear, clear_len), base));
     } else if (base == "eq_ignore_case") {
         if (is_clear) {
             std::vector<uint8_t> lower(clear, clear + clear_len);

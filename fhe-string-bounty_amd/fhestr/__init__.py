@@ -104,7 +104,7 @@ EXPORTS = [
     "fhe_str_trim_start", "fhe_str_trim_end", "fhe_str_strip", "fhe_str_replace", "fhe_str_replace_clear",
     "fhe_plan_lut_count", "fhe_plan_export_lut", "fhe_engine_set_stream", "fhe_engine_reset_stream",
     "fhe_str_len", "fhe_str_is_empty", "fhe_str_strip_prefix_clear", "fhe_str_strip_suffix_clear",
-] + [f"fhe_str_{n}{s}" for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find", "rfind", "eq_ignore_case")
+] + [f"fhe_str_{n}{s}" for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find", "rfind", "eq_ignore_case", "lt", "le", "gt", "ge")
      for s in ("", "_clear")]
 
 
@@ -187,7 +187,7 @@ def lib() -> C.CDLL:
     sig("fhe_str_is_empty", vp, vp, u32, vp)
     sig("fhe_str_strip_prefix_clear", vp, vp, u32, vp, u32, vp)
     sig("fhe_str_strip_suffix_clear", vp, vp, u32, vp, u32, vp)
-    for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find", "rfind", "eq_ignore_case"):
+    for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find", "rfind", "eq_ignore_case", "lt", "le", "gt", "ge"):
         sig(f"fhe_str_{n}", vp, vp, u32, vp, u32, vp)
         sig(f"fhe_str_{n}_clear", vp, vp, u32, vp, u32, vp)
     for n in ("trim_start", "trim_end", "strip"):
@@ -601,6 +601,10 @@ class FheStringOps:
     def find(self, a, b): return self._binary("find", a, b)
     def rfind(self, a, b): return self._binary("rfind", a, b)
     def eq_ignore_case(self, a, b): return self._binary("eq_ignore_case", a, b)[0]
+    def lt(self, a, b): return self._binary("lt", a, b)[0]
+    def le(self, a, b): return self._binary("le", a, b)[0]
+    def gt(self, a, b): return self._binary("gt", a, b)[0]
+    def ge(self, a, b): return self._binary("ge", a, b)[0]
 
     def _n_digits(self, cap):
         n = 0

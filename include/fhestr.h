@@ -173,6 +173,10 @@ FHE_STR_BINARY_DECL(contains)
 FHE_STR_BINARY_DECL(find)
 FHE_STR_BINARY_DECL(rfind)            /* last occurrence; same outputs as find */
 FHE_STR_BINARY_DECL(eq_ignore_case)   /* ASCII case folding on both sides, then eq */
+FHE_STR_BINARY_DECL(lt)               /* lexicographic (byte-wise) order, like Rust's str / Python's bytes */
+FHE_STR_BINARY_DECL(le)
+FHE_STR_BINARY_DECL(gt)
+FHE_STR_BINARY_DECL(ge)
 /* whitespace = ASCII 9..13 and 32; results are re-padded with zeros (whole string returned) */
 int fhe_str_trim_start(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
 int fhe_str_trim_end(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);

@@ -249,3 +249,12 @@ def test_len_rfind_ignore_case_strip_affix(toy_k1):
     assert _dec(toy_k1, bit)[0] == 1 and fhestr.blocks_to_string(P, _dec(toy_k1, rest)) == b"abca"
     bit, rest = ops.strip_suffix(es, b"xx")
     assert _dec(toy_k1, bit)[0] == 0 and fhestr.blocks_to_string(P, _dec(toy_k1, rest)) == s
+
+
+@pytest.mark.parametrize("a,b", [(b"abc", b"abd"), (b"abc", b"abc"), (b"abc", b"ab"), (b"", b"a"), (b"zz", b"za")])
+def test_lexicographic_order(toy_k1, a, b):
+    ops = _ops(toy_k1)
+    ea, eb = _enc(toy_k1, a, 8), _enc(toy_k1, b, 8)
+    for name, want in (("lt", a < b), ("le", a <= b), ("gt", a > b), ("ge", a >= b)):
+        assert _dec(toy_k1, getattr(ops, name)(ea, eb))[0] == int(want)
+        assert _dec(toy_k1, getattr(ops, name)(ea, b))[0] == int(want)

@@ -118,6 +118,14 @@ def test_strip_affix_offline_plan_vs_python(toy_k1, s, pat):
     assert fhestr.blocks_to_string(P, out[1:]) == (s[: len(s) - len(pat)] if s.endswith(pat) else s)
 
 
+@pytest.mark.parametrize("a,b", [(b"abc", b"abd"), (b"abc", b"abc"), (b"abc", b"ab"), (b"", b"a"), (b"", b""),
+                                  (b"b", b"abcd"), (b"zz", b"za"), (b"Abc", b"abc")])
+def test_lexicographic_order_offline_plan_vs_python(toy_k1, a, b):
+    for op, want in (("lt", a < b), ("le", a <= b), ("gt", a > b), ("ge", a >= b)):
+        assert _run(toy_k1, op, a, b)[0] == int(want), (op, "encrypted")
+        assert _run(toy_k1, op, a, ("clear", b))[0] == int(want), (op, "clear")
+
+
 def test_plan_shapes_match_survey_counts():
     # eq enc-enc 256 chars = 1024 + 69 + 5 + 1 PBS, depth 4; enc-clear = 551
     info = _plan("eq", 256, 256).info()
