@@ -258,3 +258,19 @@ def test_lexicographic_order(toy_k1, a, b):
     for name, want in (("lt", a < b), ("le", a <= b), ("gt", a > b), ("ge", a >= b)):
         assert _dec(toy_k1, getattr(ops, name)(ea, eb))[0] == int(want)
         assert _dec(toy_k1, getattr(ops, name)(ea, b))[0] == int(want)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_random_circuits_gpu_vs_clear_and_oracle(toy_k1, seed):
+    """Random lin/pbs DAGs through the GPU plan executor: decrypt == clear evaluation == oracle run."""
+    import fhestr
+    from random_circuits import build_random_circuit
+    rng = np.random.default_rng(seed)
+    plan = fhestr.Plan(gpu_engine(toy_k1))
+    evaluate = build_random_circuit(plan, rng, n_ops=60)
+    plan.finalize(1)
+    values = [int(v) for v in rng.integers(0, 4, size=6)]
+    inputs = toy_k1.ck.encrypt_many(values)
+    got = _dec(toy_k1, plan.run(inputs)).tolist()
+    assert got == evaluate(values)
+    assert got == _dec(toy_k1, run_with_oracle(plan, inputs, toy_k1.sk)).tolist()

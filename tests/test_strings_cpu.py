@@ -208,3 +208,17 @@ def test_config1_eq_8_chars_p22_cpu_reference_path(p22):
     for other, want in ((b"fhe-str!", 1), (b"fhe-str?", 0)):
         out = run_with_oracle(plan, np.concatenate([a, enc(other)]), p22.sk)
         assert p22.ck.decrypt_many(out)[0] == want
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_circuits_offline_plan_vs_clear_semantics(toy_k1, seed):
+    """Planner + leveliser on random lin/pbs DAGs: oracle-executed plan == clear evaluation."""
+    import fhestr
+    from random_circuits import build_random_circuit
+    rng = np.random.default_rng(seed)
+    plan = fhestr.Plan(None, params=to_fhestr_params(O.TOY_K1))
+    evaluate = build_random_circuit(plan, rng)
+    plan.finalize(1)
+    values = [int(v) for v in rng.integers(0, 4, size=6)]
+    out = run_with_oracle(plan, toy_k1.ck.encrypt_many(values), toy_k1.sk)
+    assert toy_k1.ck.decrypt_many(out).tolist() == evaluate(values)
