@@ -56,6 +56,9 @@ class GpuBackend:
         return self.torch.zeros((slots, self.big), dtype=self.torch.int64, device=self.device)
 
     def load_inputs(self, pool, inputs, n_inputs):
+        if isinstance(inputs, self.torch.Tensor):      # already resident in HBM (int64 view of the u64 words)
+            pool[:n_inputs].copy_(inputs.reshape(n_inputs, self.big))
+            return
         arr = np.ascontiguousarray(inputs, dtype=np.uint64).reshape(n_inputs, self.big)
         pool[:n_inputs].copy_(self.torch.from_numpy(arr.view(np.int64)))
 
