@@ -38,6 +38,9 @@ public:
     Circuit& c;
     uint32_t M, T, bits_per_block, bpc;
     bool ok;
+    // Encrypted-vs-encrypted comparisons: true = compare two blocks per PBS (see packed_pair_eq),
+    // false = the reference's one-bivariate-PBS-per-block shape (comparison.rs:10-33).
+    bool packed_compare = true;
 
     Str input_string(uint32_t cap) {
         Str s;
@@ -96,6 +99,23 @@ public:
         });
         return c.pbs(c.lin({{a, (int32_t)M}, {b, 1}}), l);
     }
+    // Two blocks per PBS: (lo_a + M*hi_a) - (lo_b + M*hi_b) lies in (-T, T); as a torus value it uses
+    // the padding bit for the sign, and a negacyclic table with f(0) = 1, f(1..T-1) = 0 returns
+    // -f(x - T) = 0 on the negative side as well, so one lookup answers "both blocks equal".
+    // (Only equality can be read this way: a table that is 1 on both signs cannot be negacyclic.)
+    uint32_t packed_pair_eq(uint32_t lo_a, uint32_t hi_a, uint32_t lo_b, uint32_t hi_b) {
+        const uint32_t l = c.lut_fn([](uint64_t x) { return (uint64_t)(x == 0); });
+        return c.pbs(c.lin({{lo_a, 1}, {hi_a, (int32_t)M}, {lo_b, -1}, {hi_b, -(int32_t)M}}, 0, (int64_t)T - 1), l);
+    }
+    // equality bits of two encrypted chars: bpc bits (reference shape) or bpc/2 bits (packed)
+    void char_eq_bits(const std::vector<uint32_t>& x, const std::vector<uint32_t>& y, std::vector<uint32_t>& out) {
+        if (packed_compare && bpc % 2 == 0) {
+            for (uint32_t k = 0; k + 1 < bpc; k += 2) out.push_back(packed_pair_eq(x[k], x[k + 1], y[k], y[k + 1]));
+        } else {
+            for (uint32_t k = 0; k < bpc; k++) out.push_back(block_eq(x[k], y[k], true));
+        }
+    }
+    uint32_t eq_bits_per_char() const { return (packed_compare && bpc % 2 == 0) ? bpc / 2 : bpc; }
     // pack_block_chunk + scalar LUT (scalar_comparison.rs:104-138,312-336,431-452): two blocks of a
     // char packed as hi*M + lo, compared with the clear value packed the same way.
     uint32_t packed_scalar_cmp(uint32_t lo, uint32_t hi, uint32_t clear, bool want_equal) {
@@ -132,13 +152,15 @@ public:
 
     // ---- whole-string equality ----
     uint32_t eq(const Str& a, const Str& b, bool want_equal) {
+        if (packed_compare && !want_equal) return not_bit(eq(a, b, true));   // ne = 1 - eq (linear)
         const uint32_t n = std::max(a.cap, b.cap);
         std::vector<uint32_t> bits;
         for (uint32_t i = 0; i < n; i++) {
             const auto* x = ch_or_null(a, i);
             const auto* y = ch_or_null(b, i);
             if (x && y) {
-                for (uint32_t k = 0; k < bpc; k++) bits.push_back(block_eq((*x)[k], (*y)[k], want_equal));
+                if (packed_compare) char_eq_bits(*x, *y, bits);
+                else for (uint32_t k = 0; k < bpc; k++) bits.push_back(block_eq((*x)[k], (*y)[k], want_equal));
             } else {
                 // the shorter string is implicitly zero padded: compare the other one's char with 0
                 std::vector<uint32_t> one;
@@ -170,8 +192,10 @@ public:
         auto key = std::make_pair(ci, pi);
         auto it = memo.find(key);
         if (it != memo.end()) return it->second;
+        std::vector<uint32_t> bits;
+        char_eq_bits(s.ch[ci], pat.ch[pi], bits);
         std::vector<Term> terms;
-        for (uint32_t k = 0; k < bpc; k++) terms.push_back({block_eq(s.ch[ci][k], pat.ch[pi][k], true), 1});
+        for (uint32_t bit : bits) terms.push_back({bit, 1});
         return memo[key] = c.lin(terms);
     }
     // t = [pat[pi] == 0] OR [s[ci] == pat[pi]]  (prefix-style match: pattern padding matches anything)
@@ -184,12 +208,12 @@ public:
         auto it = memo.find(key);
         if (it != memo.end()) return it->second;
         const uint32_t sum = char_eq_sum(s, ci, pat, pi, sums);
-        const uint32_t n = bpc;
+        const uint32_t n = eq_bits_per_char();
         uint32_t r;
         if (padding_wildcard) {
-            // value = eq_sum + (bpc+1)*z  ->  match iff value >= bpc
+            // value = eq_sum + (n+1)*z  ->  match iff value >= n
             const uint32_t l = c.lut_fn([n](uint64_t x) { return (uint64_t)(x >= n); });
-            r = c.pbs(c.lin({{sum, 1}, {z[pi], (int32_t)(bpc + 1)}}), l);
+            r = c.pbs(c.lin({{sum, 1}, {z[pi], (int32_t)(n + 1)}}), l);
         } else {
             const uint32_t l = c.lut_fn([n](uint64_t x) { return (uint64_t)(x == n); });
             r = c.pbs(sum, l);
@@ -621,10 +645,20 @@ public:
 int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t b_cap,
                     const uint8_t* clear, uint32_t clear_len) {
     StrOps s(c);
+    std::string op_name = op;
+    const std::string ref_suffix = "_reference";
+    for (const char* tail : {"_reference_clear", "_reference"}) {
+        const std::string t(tail);
+        if (op_name.size() > t.size() && op_name.compare(op_name.size() - t.size(), t.size(), t) == 0) {
+            s.packed_compare = false;          // the reference's block-by-block circuit shape
+            op_name = op_name.substr(0, op_name.size() - t.size()) + (t == "_reference_clear" ? "_clear" : "");
+            break;
+        }
+    }
     if (!s.ok) return fail("string ops need msg_mod = 2^b with b | 8 and carry_mod >= msg_mod");
     if (a_cap == 0) return fail("string capacity must be > 0");
-    const bool is_clear = op.size() > 6 && op.compare(op.size() - 6, 6, "_clear") == 0;
-    const std::string base = is_clear ? op.substr(0, op.size() - 6) : op;
+    const bool is_clear = op_name.size() > 6 && op_name.compare(op_name.size() - 6, 6, "_clear") == 0;
+    const std::string base = is_clear ? op_name.substr(0, op_name.size() - 6) : op_name;
     if (is_clear && !clear && clear_len) return fail("null clear pattern");
     Str a = s.input_string(a_cap);
     Str b;

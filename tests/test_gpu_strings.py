@@ -138,7 +138,7 @@ def test_plan_pbs_counts_match_survey():
     import fhestr
     ks = keyset(O.TOY_K1)
     eng = gpu_engine(ks)
-    info = fhestr.Plan.string_op(eng, "eq", 256, 256).info()
+    info = fhestr.Plan.string_op(eng, "eq_reference", 256, 256).info()
     assert (info["n_pbs"], info["n_levels"]) == (1099, 4)
     info = fhestr.Plan.string_op(eng, "eq_clear", 256, 0, b"x" * 200).info()
     assert (info["n_pbs"], info["n_levels"]) == (551, 4)

@@ -126,13 +126,21 @@ def test_lexicographic_order_offline_plan_vs_python(toy_k1, a, b):
         assert _run(toy_k1, op, a, ("clear", b))[0] == int(want), (op, "clear")
 
 
+@pytest.mark.parametrize("a,b", [(b"hello", b"hello"), (b"hello", b"hellp"), (b"ab", b"abc"), (b"", b""), (b"\x7f~}|", b"\x7f~}|"), (b"\x00", b"\x7f")])
+def test_reference_shaped_eq_ne_agree_with_packed(toy_k1, a, b):
+    for op, want in (("eq", a == b), ("ne", a != b), ("eq_reference", a == b), ("ne_reference", a != b)):
+        assert _run(toy_k1, op, a, b, pat_cap=8)[0] == int(want), op
+
+
 def test_plan_shapes_match_survey_counts():
     # eq enc-enc 256 chars = 1024 + 69 + 5 + 1 PBS, depth 4; enc-clear = 551
-    info = _plan("eq", 256, 256).info()
+    info = _plan("eq_reference", 256, 256).info()
     assert (info["n_pbs"], info["n_levels"], info["n_inputs"], info["n_outputs"]) == (1099, 4, 2048, 1)
+    # default: two blocks per PBS through the padding bit (fhe_string.cpp: packed_pair_eq)
+    assert _plan("eq", 256, 256).info()["n_pbs"] == 512 + 35 + 3 + 1
     info = _plan("eq_clear", 256, 0, b"x" * 200).info()
     assert (info["n_pbs"], info["n_levels"]) == (551, 4)
-    lv = [_plan("eq", 256, 256).level_info(l)["jobs"] for l in range(4)]
+    lv = [_plan("eq_reference", 256, 256).level_info(l)["jobs"] for l in range(4)]
     assert lv == [1024, 69, 5, 1]
 
 
@@ -200,7 +208,7 @@ def test_config1_eq_8_chars_p22_cpu_reference_path(p22):
     seed 0x5EED0001; "fhe-str!" vs itself -> 1, vs "fhe-str?" -> 0; 32 block PBS + 3 + 1 reduce."""
     import fhestr
     P = to_fhestr_params(O.PARAM_MESSAGE_2_CARRY_2_KS_PBS)
-    plan = fhestr.Plan.string_op(None, "eq", 8, 8, params=P)
+    plan = fhestr.Plan.string_op(None, "eq_reference", 8, 8, params=P)
     info = plan.info()
     assert (info["n_pbs"], info["n_levels"]) == (32 + 3 + 1, 3)
     enc = lambda s: p22.ck.encrypt_many(fhestr.string_to_blocks(P, s, 8))
