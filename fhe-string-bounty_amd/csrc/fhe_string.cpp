@@ -597,6 +597,18 @@ public:
         std::vector<uint32_t> signs;   // most significant first
         const uint32_t mm = M;
         for (uint32_t i = 0; i < n; i++) {
+            if (b && packed_compare && bpc % 2 == 0 && i < a.cap && i < b->cap) {
+                // sign of a packed block pair in one PBS: the sign function is odd, hence negacyclic for
+                // free -- f(0) = 0, f(1..T-1) = 1 gives -1 on the negative (padding-bit) side; +1 maps
+                // {-1, 0, 1} onto the {0, 1, 2} encoding
+                const uint32_t l = c.lut_fn([](uint64_t x) { return (uint64_t)(x != 0); });
+                for (int k = (int)bpc - 2; k >= 0; k -= 2) {
+                    const uint32_t d = c.lin({{a.ch[i][k], 1}, {a.ch[i][k + 1], (int32_t)M}, {b->ch[i][k], -1},
+                                              {b->ch[i][k + 1], -(int32_t)M}}, 0, (int64_t)T - 1);
+                    signs.push_back(c.lin({{c.pbs(d, l), 1}}, 1, 2));
+                }
+                continue;
+            }
             for (int k = (int)bpc - 1; k >= 0; k--) {
                 const bool has_a = i < a.cap;
                 if (b) {
