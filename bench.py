@@ -208,15 +208,6 @@ def main():
             sweep[str(nb)] = round(nb * 3 / (time.perf_counter() - t1), 1)
         eng.kernel_times(reset=True)
 
-    # ---- FheString ms/op (BASELINE.json configs 3 and 4): level batches sharded over the ranks,
-    #      one RCCL all-gather per level; single GPU = same code with world 1 ----
-    string_ops = None
-    if not args.no_strings:
-        try:
-            string_ops = bench_strings(fhestr, eng, ck, P, rank, world, local_rank)
-        except Exception as e:   # never let the secondary section take the headline number down
-            string_ops = {"error": f"{type(e).__name__}: {e}"}
-
     if rank == 0:
         total_pbs = B * world * args.steps
         value = total_pbs / elapsed
@@ -250,9 +241,34 @@ def main():
             "whole_pbs_hbm_model": {"bytes_per_pbs": pbs_bytes,
                                     "frac_of_peak": value * pbs_bytes / (world * HBM_PEAK_GBS * 1e9)},
             "verified_decrypt": verified,
-            "string_ops": string_ops,
+            "string_ops": None,
             "batch_sweep_pbs_per_s": sweep,
         }
+
+    # ---- FheString ms/op (BASELINE.json configs 3 and 4): level batches sharded over the ranks, one
+    #      RCCL all-gather per level; single GPU = same code with world 1.  A watchdog makes sure the
+    #      headline line is printed even if a collective of this secondary section were to hang. ----
+    if not args.no_strings:
+        import threading
+
+        def bail():
+            if rank == 0:
+                rec["string_ops"] = {"error": "timeout: FheString section did not finish in 180 s"}
+                print(json.dumps(rec), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(180.0, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            string_ops = bench_strings(fhestr, eng, ck, P, rank, world, local_rank)
+        except Exception as e:   # never let the secondary section take the headline number down
+            string_ops = {"error": f"{type(e).__name__}: {e}"}
+        dog.cancel()
+        if rank == 0:
+            rec["string_ops"] = string_ops
+
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             try:
                 cb, cpu_out = cpu_baseline(P, bsk, ksk, cts, tables, sel)
