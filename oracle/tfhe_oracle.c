@@ -194,6 +194,7 @@ struct orc_fft {
     double *st_re, *st_im;   /* per-stage twiddles, stage with half-size h stored at offset h: exp(-2 pi i j / (2h)) */
     uint32_t *rev;
     double *sc_re, *sc_im;   /* scratch planes (one plan per thread) */
+    double *sc2_re, *sc2_im; /* ping-pong planes of the Stockham stages */
 };
 
 orc_fft *orc_fft_new(uint32_t N) {
@@ -207,6 +208,8 @@ orc_fft *orc_fft_new(uint32_t N) {
     f->st_im = (double *)aligned_alloc(64, sizeof(double) * 2 * n);
     f->sc_re = (double *)aligned_alloc(64, sizeof(double) * n);
     f->sc_im = (double *)aligned_alloc(64, sizeof(double) * n);
+    f->sc2_re = (double *)aligned_alloc(64, sizeof(double) * n);
+    f->sc2_im = (double *)aligned_alloc(64, sizeof(double) * n);
     f->rev = (uint32_t *)malloc(sizeof(uint32_t) * n);
     double unit = M_PI / (2.0 * (double)n);
     for (uint32_t i = 0; i < n; i++) {
@@ -234,37 +237,78 @@ orc_fft *orc_fft_new(uint32_t N) {
 void orc_fft_free(orc_fft *f) {
     if (!f) return;
     free(f->tw_re); free(f->tw_im); free(f->st_re); free(f->st_im);
-    free(f->sc_re); free(f->sc_im); free(f->rev);
+    free(f->sc_re); free(f->sc_im); free(f->sc2_re); free(f->sc2_im); free(f->rev);
     free(f);
 }
 
-/* in-place complex FFT on split planes (bit-reversed input order expected by the caller: the
- * data in re/im must already be permuted by f->rev); sign < 0 forward, > 0 inverse (conj twiddles).
- * Plain radix-2 decimation in time; the j loops are contiguous so gcc vectorises them. */
+/* Complex FFT on split planes, Stockham autosort (no bit reversal): every stage reads plane set x and
+ * writes plane set y with unit-stride inner loops, which gcc vectorises.  Radix-4 stages, one radix-2
+ * stage when log2(n) is odd.  sign < 0: e^{-2 pi i jk/n} (forward); sign > 0: conjugate (inverse).
+ * Result ends in (re, im).  Twiddles e^{-2 pi i p / (l*r)} are read from the per-stage tables built in
+ * orc_fft_new (st_* hold exp(-pi i j / h) at offset h). */
 static void cfft_planes(const orc_fft *f, double *restrict re, double *restrict im, int sign) {
     const uint32_t n = f->n;
-    for (uint32_t h = 1; h < n; h <<= 1) {
-        const double *restrict wr = f->st_re + h;
-        const double *restrict wi0 = f->st_im + h;
-        for (uint32_t s = 0; s < n; s += 2 * h) {
-            double *restrict ar = re + s, *restrict ai = im + s;
-            double *restrict br = re + s + h, *restrict bi = im + s + h;
-            if (sign < 0) {
-                for (uint32_t j = 0; j < h; j++) {
-                    double xr = br[j] * wr[j] - bi[j] * wi0[j];
-                    double xi = br[j] * wi0[j] + bi[j] * wr[j];
-                    br[j] = ar[j] - xr; bi[j] = ai[j] - xi;
-                    ar[j] += xr; ai[j] += xi;
-                }
-            } else {
-                for (uint32_t j = 0; j < h; j++) {
-                    double xr = br[j] * wr[j] + bi[j] * wi0[j];
-                    double xi = bi[j] * wr[j] - br[j] * wi0[j];
-                    br[j] = ar[j] - xr; bi[j] = ai[j] - xi;
-                    ar[j] += xr; ai[j] += xi;
+    double *xr = re, *xi = im, *yr = f->sc2_re, *yi = f->sc2_im;
+    uint32_t nc = n;         /* current sub-transform length */
+    uint32_t st = 1;         /* stride = number of interleaved sub-transforms */
+    const double sg = sign < 0 ? 1.0 : -1.0;
+    while (nc > 1) {
+        if (nc % 4 == 0) {
+            const uint32_t n1 = nc / 4;
+            for (uint32_t p = 0; p < n1; p++) {
+                /* w1 = exp(-+2 pi i p / nc) = table entry p at offset nc/2 */
+                const double w1r = f->st_re[nc / 2 + p], w1i = sg * f->st_im[nc / 2 + p];
+                const double w2r = w1r * w1r - w1i * w1i, w2i = 2.0 * w1r * w1i;
+                const double w3r = w2r * w1r - w2i * w1i, w3i = w2r * w1i + w2i * w1r;
+                const double *restrict ar = xr + (size_t)st * (p + 0 * n1), *restrict ai = xi + (size_t)st * (p + 0 * n1);
+                const double *restrict br = xr + (size_t)st * (p + 1 * n1), *restrict bi = xi + (size_t)st * (p + 1 * n1);
+                const double *restrict cr = xr + (size_t)st * (p + 2 * n1), *restrict ci = xi + (size_t)st * (p + 2 * n1);
+                const double *restrict dr = xr + (size_t)st * (p + 3 * n1), *restrict di = xi + (size_t)st * (p + 3 * n1);
+                double *restrict y0r = yr + (size_t)st * (4 * p + 0), *restrict y0i = yi + (size_t)st * (4 * p + 0);
+                double *restrict y1r = yr + (size_t)st * (4 * p + 1), *restrict y1i = yi + (size_t)st * (4 * p + 1);
+                double *restrict y2r = yr + (size_t)st * (4 * p + 2), *restrict y2i = yi + (size_t)st * (4 * p + 2);
+                double *restrict y3r = yr + (size_t)st * (4 * p + 3), *restrict y3i = yi + (size_t)st * (4 * p + 3);
+                for (uint32_t q = 0; q < st; q++) {
+                    const double apcr = ar[q] + cr[q], apci = ai[q] + ci[q];
+                    const double amcr = ar[q] - cr[q], amci = ai[q] - ci[q];
+                    const double bpdr = br[q] + dr[q], bpdi = bi[q] + di[q];
+                    /* jbmd = (+-i) * (b - d): forward uses -i on the odd outputs, see below */
+                    const double bmdr = br[q] - dr[q], bmdi = bi[q] - di[q];
+                    const double jr = -sg * bmdi, ji = sg * bmdr;      /* (sg * i) * (b - d) */
+                    y0r[q] = apcr + bpdr; y0i[q] = apci + bpdi;
+                    const double t2r = apcr - bpdr, t2i = apci - bpdi;
+                    y2r[q] = t2r * w2r - t2i * w2i; y2i[q] = t2r * w2i + t2i * w2r;
+                    const double t1r = amcr - jr, t1i = amci - ji;
+                    y1r[q] = t1r * w1r - t1i * w1i; y1i[q] = t1r * w1i + t1i * w1r;
+                    const double t3r = amcr + jr, t3i = amci + ji;
+                    y3r[q] = t3r * w3r - t3i * w3i; y3i[q] = t3r * w3i + t3i * w3r;
                 }
             }
+            nc = n1;
+            st *= 4;
+        } else {
+            const uint32_t m = nc / 2;
+            for (uint32_t p = 0; p < m; p++) {
+                const double wr = f->st_re[nc / 2 + p], wi = sg * f->st_im[nc / 2 + p];
+                const double *restrict ar = xr + (size_t)st * p, *restrict ai = xi + (size_t)st * p;
+                const double *restrict br = xr + (size_t)st * (p + m), *restrict bi = xi + (size_t)st * (p + m);
+                double *restrict y0r = yr + (size_t)st * (2 * p), *restrict y0i = yi + (size_t)st * (2 * p);
+                double *restrict y1r = yr + (size_t)st * (2 * p + 1), *restrict y1i = yi + (size_t)st * (2 * p + 1);
+                for (uint32_t q = 0; q < st; q++) {
+                    const double dr = ar[q] - br[q], di = ai[q] - bi[q];
+                    y0r[q] = ar[q] + br[q]; y0i[q] = ai[q] + bi[q];
+                    y1r[q] = dr * wr - di * wi; y1i[q] = dr * wi + di * wr;
+                }
+            }
+            nc = m;
+            st *= 2;
         }
+        double *tr = xr, *ti = xi;
+        xr = yr; xi = yi; yr = tr; yi = ti;
+    }
+    if (xr != re) {
+        memcpy(re, xr, sizeof(double) * n);
+        memcpy(im, xi, sizeof(double) * n);
     }
 }
 
@@ -274,9 +318,8 @@ static void fft_forward(const orc_fft *f, double *out, const uint64_t *poly, dou
     for (uint32_t j = 0; j < n; j++) {
         double a = (double)(int64_t)poly[j] * scale;       /* into_signed().cast_into() */
         double b = (double)(int64_t)poly[j + n] * scale;
-        uint32_t r = f->rev[j];
-        re[r] = a * f->tw_re[j] - b * f->tw_im[j];
-        im[r] = a * f->tw_im[j] + b * f->tw_re[j];
+        re[j] = a * f->tw_re[j] - b * f->tw_im[j];
+        im[j] = a * f->tw_im[j] + b * f->tw_re[j];
     }
     cfft_planes(f, re, im, -1);
     for (uint32_t j = 0; j < n; j++) {
@@ -296,9 +339,8 @@ void orc_fft_add_backward_as_torus(const orc_fft *f, uint64_t *poly, double *d) 
     const uint32_t n = f->n;
     double *re = f->sc_re, *im = f->sc_im;
     for (uint32_t j = 0; j < n; j++) {
-        uint32_t r = f->rev[j];
-        re[r] = d[2 * j];
-        im[r] = d[2 * j + 1];
+        re[j] = d[2 * j];
+        im[j] = d[2 * j + 1];
     }
     cfft_planes(f, re, im, +1);
     const double norm = 1.0 / (double)n;
