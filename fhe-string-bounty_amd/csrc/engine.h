@@ -41,12 +41,12 @@ struct Engine {
     uint32_t n_luts = 0;
 
     // staging / scratch (grown on demand)
-    uint64_t *d_in = nullptr, *d_small = nullptr, *d_out = nullptr, *d_pool = nullptr;
+    uint64_t *d_in = nullptr, *d_small = nullptr, *d_small2 = nullptr, *d_out = nullptr, *d_pool = nullptr;
     uint32_t* d_idx = nullptr;
     void* d_meta = nullptr;
     void* d_ws = nullptr;      // per-LWE HBM workspace of the large-N blind rotation
     size_t cap_ws = 0;
-    size_t cap_in = 0, cap_small = 0, cap_out = 0, cap_idx = 0, cap_pool = 0, cap_meta = 0;
+    size_t cap_in = 0, cap_small = 0, cap_small2 = 0, cap_out = 0, cap_idx = 0, cap_pool = 0, cap_meta = 0;
 
     static int create(const fhe_params_t& p, int device, Engine** out);
     ~Engine();

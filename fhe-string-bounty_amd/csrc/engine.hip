@@ -169,7 +169,7 @@ Engine::~Engine() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     auto rel = [](void* ptr) { if (ptr) (void)hipFree(ptr); };
-    rel(d_ksk); rel(d_ksk_packed); rel(d_fbsk); rel(d_luts); rel(d_in); rel(d_small); rel(d_out); rel(d_idx);
+    rel(d_ksk); rel(d_ksk_packed); rel(d_fbsk); rel(d_luts); rel(d_in); rel(d_small); rel(d_small2); rel(d_out); rel(d_idx);
     rel(d_pool); rel(d_meta); rel(d_ws);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ring) if (e) (void)hipEventDestroy(e);
@@ -334,6 +334,8 @@ int Engine::ensure_batch(uint32_t count) {
 
 int Engine::launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t count) {
     if (!d_ksk && !d_ksk_packed) return fail("keys not loaded");
+    // grid.y = sample tiles; HIP caps grid.y at 65535
+    if (count > 65535u * KSD_S) return fail("batch too large for one keyswitch launch (max 524280 LWEs)");
     const uint32_t in_dim = p.k * p.N, out_size = p.n + 1;
     HIP_TRY(hipMemsetAsync(d_sm, 0, (size_t)count * out_size * 8, stream));
     if (d_ksk_packed) {
@@ -450,20 +452,14 @@ int Engine::pbs_ks_host(const uint64_t* in_small, const uint32_t* lut_idx, uint6
     if (check_lut_idx(lut_idx, count)) return 1;
     if (ensure_batch(count)) return 1;
     const size_t small = (size_t)p.n + 1;
-    uint64_t* d_small2 = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_small2, count * small * 8));
+    if (ensure((void**)&d_small2, &cap_small2, count * small * 8)) return 1;
     HIP_TRY(hipMemcpyAsync(d_small, in_small, count * small * 8, hipMemcpyHostToDevice, stream));
     if (lut_idx) HIP_TRY(hipMemcpyAsync(d_idx, lut_idx, (size_t)count * 4, hipMemcpyHostToDevice, stream));
-    int rc = launch_blind_rotate(d_small, lut_idx ? d_idx : nullptr, d_out, count);
-    if (!rc) rc = launch_keyswitch(d_out, d_small2, count);
-    if (!rc) {
-        hipError_t e = hipMemcpyAsync(out_small, d_small2, count * small * 8, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) rc = fail(std::string("pbs_ks copy back: ") + hipGetErrorString(e));
-    }
-    (void)hipStreamSynchronize(stream);
-    (void)hipFree(d_small2);
-    return rc;
+    if (launch_blind_rotate(d_small, lut_idx ? d_idx : nullptr, d_out, count)) return 1;
+    if (launch_keyswitch(d_out, d_small2, count)) return 1;
+    HIP_TRY(hipMemcpyAsync(out_small, d_small2, count * small * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
 }
 
 int Engine::lincomb_dev(const uint64_t* d_pool_, const uint32_t* d_off, const uint32_t* d_src,

@@ -128,6 +128,7 @@ __device__ __forceinline__ void small_dft(cplx* x) {
 // Compile-time description of the pass structure for P points with R per thread.
 template <int LP, int LR>
 struct FftPlan {
+    static constexpr bool SWAP = false;
     static constexpr int LOGP = LP;
     static constexpr int LOGR = LR;
     static constexpr int P = 1 << LOGP;
@@ -141,6 +142,48 @@ struct FftPlan {
     // log2 of sub-transform size at the start of pass s
     __host__ __device__ static constexpr int log_S(int s) { return LOGP - (s < FULL ? s : FULL) * LOGR; }
 };
+
+// P = 1024 points, 4 per thread, 256 threads (4 waves): the plan PARAM_MESSAGE_2_CARRY_2 (N = 2048)
+// runs on.  Same radix-4 decimation-in-frequency passes as FftPlan<10, 2>, but two of the four
+// inter-pass exchanges never touch LDS: a 4x4 transpose between the thread's 4 registers and lane
+// bits (5,4) is two rounds of v_permlane32_swap / v_permlane16_swap (gfx950), ~8 cycles per dword on
+// the VALU against ~25 (ds_write_b64) + ~9 (ds_read_b64) per 8-byte exchange through LDS, whose
+// write port (~94 B/clk/CU) is what the CMUX loop saturates first.
+//
+// Index bits of point j = (b9..b0), frequency f = k0 + 4 k1 + 16 k2 + 64 k3 + 256 k4:
+//   start        regs b9b8 | wave b7b6 | lane(5,4) b5b4 | lane(3..0) b3..b0       (j = tau + 256 m)
+//   pass 1  -> k0, LDS transpose regs <-> wave        (workgroup barrier; rows of 64 slots)
+//   pass 2  -> k1, register/lane(5,4) swap
+//   pass 3  -> k2, wave-local LDS exchange            (regs b3b2, lane(5,4) b1b0, lane(3..0) k1k2)
+//   pass 4  -> k3, register/lane(5,4) swap
+//   pass 5  -> k4                                     (regs k4 | wave k0 | lane(5,4) k3 | lane(3..0) k1k2)
+// The inverse walks the same steps backwards.  Plane rows (64 slots each, 16 per plane): wave w owns
+// the "slab" rows 4w..4w+3 between the inverse's last read and the forward's first write, and the
+// "comb" rows {w, w+4, w+8, w+12} in between, so the only workgroup barriers are the two slab<->comb
+// transposes.  Two transforms of the same direction on the same planes need a barrier between them
+// (alternating forward/inverse, as the CMUX loop does, needs none).
+struct FftSwap10 {
+    static constexpr bool SWAP = true;
+    static constexpr int LOGP = 10;
+    static constexpr int LOGR = 2;
+    static constexpr int P = 1024;
+    static constexpr int R = 4;
+    static constexpr int T = 256;
+    static constexpr int FULL = 5;
+    static constexpr int LOGLAST = 0;
+    static constexpr int NP = 5;
+    static constexpr int NTW = 4;
+    __host__ __device__ static constexpr int log_radix(int) { return 2; }
+    __host__ __device__ static constexpr int log_S(int s) { return 10 - 2 * s; }
+};
+
+// Plan used by the blind-rotation kernels for (log2 P, log2 R).
+template <int LP, int LR>
+struct PlanFor { using type = FftPlan<LP, LR>; };
+#ifndef FHESTR_NO_SWAP_FFT
+template <>
+struct PlanFor<10, 2> { using type = FftSwap10; };
+#endif
 
 // ---- LDS slot swizzle (8-byte slots) ----------------------------------------------------------
 // ds_read_b64 serves a wave as two 32-lane groups (32 distinct slots mod 32 = conflict free),
@@ -221,7 +264,8 @@ __device__ __forceinline__ void fft_init_consts(FftConsts<PL>& c, int tau) {
     for (int s = 0; s < PL::NTW; s++) {
         const int lS = PL::log_S(s);
         const int lS1 = lS - PL::LOGR;
-        const int tp = tau & ((1 << lS1) - 1);
+        int tp = tau & ((1 << lS1) - 1);
+        if (PL::SWAP && s == 3) tp = (tau >> 4) & 3;     // pass 4 runs with b1b0 in lane bits (5,4)
 #pragma unroll
         for (int q = 0; q < PL::R; q++) {
             double sn, cs;
@@ -233,11 +277,144 @@ __device__ __forceinline__ void fft_init_consts(FftConsts<PL>& c, int tau) {
     }
 }
 
+// ---- FftSwap10 building blocks --------------------------------------------------------------
+__device__ __forceinline__ void wave_local_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <bool ROW16>
+__device__ __forceinline__ void swap_halves(double& a, double& b) {
+    // ROW16: a[lanes with bit 4 set] <-> b[lanes with bit 4 clear]; else the same on lane bit 5
+    const unsigned alo = __double2loint(a), ahi = __double2hiint(a);
+    const unsigned blo = __double2loint(b), bhi = __double2hiint(b);
+    if (ROW16) {
+        const auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        a = __hiloint2double(h[0], l[0]);
+        b = __hiloint2double(h[1], l[1]);
+    } else {
+        const auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        a = __hiloint2double(h[0], l[0]);
+        b = __hiloint2double(h[1], l[1]);
+    }
+}
+// 4x4 transpose between register index (2 bits) and lane bits (5,4); its own inverse.
+__device__ __forceinline__ void swap_regs_lanes(cplx* x) {
+    swap_halves<false>(x[0].re, x[2].re); swap_halves<false>(x[0].im, x[2].im);
+    swap_halves<false>(x[1].re, x[3].re); swap_halves<false>(x[1].im, x[3].im);
+    swap_halves<true>(x[0].re, x[1].re);  swap_halves<true>(x[0].im, x[1].im);
+    swap_halves<true>(x[2].re, x[3].re);  swap_halves<true>(x[2].im, x[3].im);
+}
+// slab <-> comb transposes (regs <-> wave).  Slot = row * 64 + lane: conflict free as is.
+__device__ __forceinline__ int swap10_slab(int tau, int r) { return (((tau >> 6) * 4 + r) << 6) | (tau & 63); }
+__device__ __forceinline__ int swap10_comb(int tau, int r) { return ((r * 4 + (tau >> 6)) << 6) | (tau & 63); }
+// Wave-local exchange inside the wave's comb rows.  Side A: regs k2 | lane(5,4) k1 | lane(3..0) b3..b0;
+// side B: regs b3b2 | lane(5,4) b1b0 | lane(3..0) k1hi k1lo k2hi k2lo.  Slot within the 4 comb rows:
+//   c0 = b0^k1lo  c1 = b1^k1hi  c2 = b2^k2hi  c3 = b3^k2lo  c4 = k1lo  c5 = k1hi  row = k2
+// -- every 16-lane group of either side covers 16 distinct slots mod 16 and every 32-lane group 32
+// distinct slots mod 32 (the ds_write_b64 / ds_read_b64 conflict-free conditions).
+__device__ __forceinline__ int swap10_side_a(int tau, int r) {
+    const int lane = tau & 63, w = tau >> 6;
+    const int c = lane ^ ((lane >> 4) & 1) ^ (((lane >> 5) & 1) << 1) ^ ((r >> 1) << 2) ^ ((r & 1) << 3);
+    return ((w + 4 * r) << 6) | c;
+}
+__device__ __forceinline__ int swap10_side_b(int tau, int r) {
+    const int lane = tau & 63, w = tau >> 6;
+    const int l0 = lane & 1, l1 = (lane >> 1) & 1, l2 = (lane >> 2) & 1, l3 = (lane >> 3) & 1;
+    const int l4 = (lane >> 4) & 1, l5 = (lane >> 5) & 1;
+    const int c = (l4 ^ l2) | ((l5 ^ l3) << 1) | (((r & 1) ^ l1) << 2) | (((r >> 1) ^ l0) << 3) | (l2 << 4) | (l3 << 5);
+    return ((w + 4 * (lane & 3)) << 6) | c;
+}
+template <bool INV>
+__device__ __forceinline__ void swap10_twiddle(cplx* x, const cplx* tw) {
+#pragma unroll
+    for (int q = 1; q < 4; q++) x[q] = INV ? cmul_conj(x[q], tw[q]) : cmul(x[q], tw[q]);
+}
+
+// NPOLY polynomials carried by the same threads (planes of polynomial p at re0 + p*poly_stride,
+// imaginary plane im_off slots further): one workgroup barrier serves all of them.
+template <int NPOLY>
+__device__ __forceinline__ void swap10_forward(cplx (*x)[4], const FftConsts<FftSwap10>& c, double* re0,
+                                               int poly_stride, int im_off, int tau) {
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) {
+        double* re = re0 + p * poly_stride;
+        double* im = re + im_off;
+        small_dft<4, false>(x[p]);
+        swap10_twiddle<false>(x[p], c.tw[0]);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int a = swap10_slab(tau, r); re[a] = x[p][r].re; im[a] = x[p][r].im; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) {
+        double* re = re0 + p * poly_stride;
+        double* im = re + im_off;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int a = swap10_comb(tau, r); x[p][r].re = re[a]; x[p][r].im = im[a]; }
+        small_dft<4, false>(x[p]);
+        swap10_twiddle<false>(x[p], c.tw[1]);
+        swap_regs_lanes(x[p]);
+        small_dft<4, false>(x[p]);
+        swap10_twiddle<false>(x[p], c.tw[2]);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int a = swap10_side_a(tau, r); re[a] = x[p][r].re; im[a] = x[p][r].im; }
+        wave_local_fence();
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int a = swap10_side_b(tau, r); x[p][r].re = re[a]; x[p][r].im = im[a]; }
+        small_dft<4, false>(x[p]);
+        swap10_twiddle<false>(x[p], c.tw[3]);
+        swap_regs_lanes(x[p]);
+        small_dft<4, false>(x[p]);
+    }
+}
+template <int NPOLY>
+__device__ __forceinline__ void swap10_inverse(cplx (*x)[4], const FftConsts<FftSwap10>& c, double* re0,
+                                               int poly_stride, int im_off, int tau) {
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) {
+        double* re = re0 + p * poly_stride;
+        double* im = re + im_off;
+        small_dft<4, true>(x[p]);
+        swap_regs_lanes(x[p]);
+        swap10_twiddle<true>(x[p], c.tw[3]);
+        small_dft<4, true>(x[p]);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int a = swap10_side_b(tau, r); re[a] = x[p][r].re; im[a] = x[p][r].im; }
+        wave_local_fence();
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int a = swap10_side_a(tau, r); x[p][r].re = re[a]; x[p][r].im = im[a]; }
+        swap10_twiddle<true>(x[p], c.tw[2]);
+        small_dft<4, true>(x[p]);
+        swap_regs_lanes(x[p]);
+        swap10_twiddle<true>(x[p], c.tw[1]);
+        small_dft<4, true>(x[p]);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int a = swap10_comb(tau, r); re[a] = x[p][r].re; im[a] = x[p][r].im; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) {
+        double* re = re0 + p * poly_stride;
+        double* im = re + im_off;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int a = swap10_slab(tau, r); x[p][r].re = re[a]; x[p][r].im = im[a]; }
+        swap10_twiddle<true>(x[p], c.tw[0]);
+        small_dft<4, true>(x[p]);
+    }
+}
+
 // Forward transform.  In: x[m] = point (tau + T*m) of the (already twisted) input.
 // Out: x[rho] in last-pass layout.  `re`/`im` are this group's LDS planes (P doubles each).
 template <class PL>
 __device__ __forceinline__ void fft_forward(cplx* x, const FftConsts<PL>& c, double* re, double* im,
                                             int tau) {
+    if constexpr (PL::SWAP) {
+        swap10_forward<1>(reinterpret_cast<cplx(*)[4]>(x), c, re, 0, (int)(im - re), tau);
+        return;
+    }
     constexpr int R = PL::R;
 #pragma unroll
     for (int s = 0; s < PL::NP; s++) {
@@ -286,6 +463,10 @@ __device__ __forceinline__ void fft_forward(cplx* x, const FftConsts<PL>& c, dou
 template <class PL>
 __device__ __forceinline__ void fft_inverse(cplx* x, const FftConsts<PL>& c, double* re, double* im,
                                             int tau) {
+    if constexpr (PL::SWAP) {
+        swap10_inverse<1>(reinterpret_cast<cplx(*)[4]>(x), c, re, 0, (int)(im - re), tau);
+        return;
+    }
     constexpr int R = PL::R;
 #pragma unroll
     for (int s = PL::NP - 1; s >= 0; s--) {
@@ -396,6 +577,10 @@ __device__ __forceinline__ bool pass_sync_is_wave_local(int log_S_next) { return
 template <class PL, int NPOLY>
 __device__ __forceinline__ void fft_forward_multi(cplx (*x)[PL::R], const FftConsts<PL>& c, double* re0,
                                                   int poly_stride, int im_off, int tau) {
+    if constexpr (PL::SWAP) {
+        swap10_forward<NPOLY>(x, c, re0, poly_stride, im_off, tau);
+        return;
+    }
     bool loaded = true;   // pass 0 operands are already in registers
 #pragma unroll
     for (int s = 0; s < PL::NP; s++) {
@@ -424,6 +609,10 @@ __device__ __forceinline__ void fft_forward_multi(cplx (*x)[PL::R], const FftCon
 template <class PL, int NPOLY>
 __device__ __forceinline__ void fft_inverse_multi(cplx (*x)[PL::R], const FftConsts<PL>& c, double* re0,
                                                   int poly_stride, int im_off, int tau) {
+    if constexpr (PL::SWAP) {
+        swap10_inverse<NPOLY>(x, c, re0, poly_stride, im_off, tau);
+        return;
+    }
     bool loaded = true;   // last-pass operands are in registers
 #pragma unroll
     for (int s = PL::NP - 1; s >= 0; s--) {

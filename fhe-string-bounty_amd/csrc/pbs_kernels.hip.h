@@ -72,7 +72,8 @@ __device__ __forceinline__ int32_t decomp_next_digit64(uint64_t& state, uint32_t
 __device__ __forceinline__ int32_t decomp_single_digit(uint64_t x, uint32_t b) {
     const uint32_t t = (uint32_t)(x >> 32) >> (31 - b);          // b+1 top bits (b <= 31)
     const uint32_t res = ((t + 1u) >> 1) & ((1u << b) - 1u);
-    return (int32_t)res - (int32_t)(res > (1u << (b - 1)) ? (1u << b) : 0u);
+    const uint32_t carry = ((res - 1u) & res) >> (b - 1);          // [res > B/2], select-free
+    return (int32_t)(res - (carry << b));
 }
 // fft_impl/common.rs:26-43 (offset 0, lut_count_log 0): result in [0, 2N]
 __device__ __forceinline__ uint32_t modulus_switch(uint64_t x, int logN) {
@@ -84,7 +85,7 @@ template <int LOGN, int LOGR, int K1, int L>
 struct BrCfg {
     static constexpr int N = 1 << LOGN;
     static constexpr int P = N / 2;
-    using PL = FftPlan<LOGN - 1, LOGR>;
+    using PL = typename PlanFor<LOGN - 1, LOGR>::type;
     static constexpr int R = PL::R;
     static constexpr int T = PL::T;
     static constexpr int THREADS = K1 * T;
@@ -223,7 +224,7 @@ blind_rotate_kernel(BlindRotateArgs args) {
         d_next = lds_d[i + 1 < n ? i + 1 : i];                  // prefetch (LDS broadcast read)
         if (d == 0xFFFFFFFFu) continue;                          // block-uniform
         const uint32_t rem = d & (N - 1);
-        const bool odd = (d >> LOGN) & 1;
+        const int32_t oddmask = -(int32_t)((d >> LOGN) & 1);
 
         // Fourier GGSW rows of the last decomposition level handled first (ggsw.rs:524): issue the
         // global loads now, they land while the forward FFT runs (L2 / Infinity-Cache resident key)
@@ -247,9 +248,9 @@ blind_rotate_kernel(BlindRotateArgs args) {
             for (int h = 0; h < 2; h++) {
                 const uint32_t j = tau + T * m + h * P;
                 const uint32_t src = (j - rem) & (N - 1);        // (acc*X^d)[j] = +-acc[j - rem]
-                const bool neg = (j < rem) != odd;
-                uint64_t v = my_acc[src];
-                v = neg ? (0 - v) : v;
+                // sign mask without selects: all-ones iff (j < rem) != odd  (j, rem < 2^31)
+                const uint64_t sm = (uint64_t)(int64_t)(int32_t)(((int32_t)(j - rem) >> 31) ^ oddmask);
+                const uint64_t v = (my_acc[src] ^ sm) - sm;
                 const uint64_t own = h == 0 ? acc_lo[m] : acc_hi[m];
                 const uint32_t st = L == 1 ? (uint32_t)decomp_single_digit(v - own, bL) : decomp_init_state(v - own, bL);
                 if (h == 0) st_lo[m] = st; else st_hi[m] = st;
@@ -353,7 +354,7 @@ template <int LOGN, int LOGR, int K1, int L>
 struct BrWideCfg {
     static constexpr int N = 1 << LOGN;
     static constexpr int P = N / 2;
-    using PL = FftPlan<LOGN - 1, LOGR>;
+    using PL = typename PlanFor<LOGN - 1, LOGR>::type;
     static constexpr int R = PL::R;
     static constexpr int T = PL::T;
     static constexpr int THREADS = T;
@@ -428,7 +429,7 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
         d_next = lds_d[i + 1 < n ? i + 1 : i];
         if (d == 0xFFFFFFFFu) continue;
         const uint32_t rem = d & (N - 1);
-        const bool odd = (d >> LOGN) & 1;
+        const int32_t oddmask = -(int32_t)((d >> LOGN) & 1);
         const double2* bk0 = fbsk + (size_t)i * GGSW_ELEMS;
 
         double2 bpre[CFG::PREFETCH_ALL ? K1 : 1][CFG::PREFETCH_ALL ? K1 : 1][R];
@@ -452,9 +453,8 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
                 for (int h = 0; h < 2; h++) {
                     const uint32_t j = tau + T * m + h * P;
                     const uint32_t src = (j - rem) & (N - 1);
-                    const bool neg = (j < rem) != odd;
-                    uint64_t v = lds_acc[(size_t)p * N + src];
-                    v = neg ? (0 - v) : v;
+                    const uint64_t sm = (uint64_t)(int64_t)(int32_t)(((int32_t)(j - rem) >> 31) ^ oddmask);
+                    const uint64_t v = (lds_acc[(size_t)p * N + src] ^ sm) - sm;
                     const uint64_t own = h == 0 ? acc_lo[p][m] : acc_hi[p][m];
                     const uint32_t st = L == 1 ? (uint32_t)decomp_single_digit(v - own, bL) : decomp_init_state(v - own, bL);
                     if (h == 0) st_lo[p][m] = st; else st_hi[p][m] = st;

@@ -316,3 +316,48 @@ def test_p22_output_noise_matches_oracle(p22):
           f"delta/2 = 2^{np.log2(params.delta / 2):.0f}")
     assert 0.6 < s_gpu / s_fft < 1.6
     assert abs(e_gpu.mean()) < 4 * s_gpu / np.sqrt(len(e_gpu)) + 1.0   # unbiased
+
+
+@pytest.mark.parametrize("B", [1, 3, 255, 257, 600], ids=lambda b: f"B{b}")
+def test_ragged_batch_sizes(toy_k1, B):
+    """Batch sizes around the one-LWE-per-CU boundary (256 CUs) and the kernels' sample tiles; per-LWE
+    LUT choice.  Keyswitch stays bit-exact, the PBS decrypt-exact."""
+    ks = toy_k1
+    eng = gpu_engine(ks)
+    p = ks.params
+    M = p.msg_mod * p.carry_mod
+    luts = [ks.sk.generate_lookup_table(f)[0] for f in (lambda x: x, lambda x: (x + 1) % M, lambda x: (3 * x) % M)]
+    ids = np.array([eng.upload_lut(l) for l in luts], dtype=np.uint32)
+    rng = np.random.default_rng(B)
+    msgs = rng.integers(0, M, size=B)
+    sel = rng.integers(0, 3, size=B)
+    cts = ks.ck.encrypt_many(msgs, O.Rng(77, B))
+    assert np.array_equal(eng.keyswitch(cts), np.stack([ks.sk.keyswitch(c) for c in cts]))
+    got = ks.ck.decrypt_many(eng.apply_lookup_table(cts, ids[sel]))
+    want = np.where(sel == 0, msgs, np.where(sel == 1, (msgs + 1) % M, (3 * msgs) % M))
+    assert np.array_equal(got, want)
+
+
+def test_empty_batches_and_error_reporting(toy_k1):
+    """Empty inputs are no-ops; bad LUT ids, missing keys and missing LUTs are reported, not run."""
+    import fhestr
+    from conftest import to_fhestr_params
+    ks = toy_k1
+    eng = gpu_engine(ks)
+    p = ks.params
+    empty_big = np.zeros((0, p.big_size), dtype=np.uint64)
+    assert eng.keyswitch(empty_big).shape == (0, p.small_size)
+    assert eng.apply_lookup_table(empty_big, np.zeros(0, dtype=np.uint32)).shape == (0, p.big_size)
+    assert eng.pbs(np.zeros((0, p.small_size), dtype=np.uint64), np.zeros(0, dtype=np.uint32)).shape == (0, p.big_size)
+    cts = ks.ck.encrypt_many([1, 2])
+    with pytest.raises(fhestr.FheError, match="lut_idx"):
+        eng.apply_lookup_table(cts, np.array([0, 10**6], dtype=np.uint32))
+    fresh = fhestr.Engine(to_fhestr_params(p), 0)
+    try:
+        with pytest.raises(fhestr.FheError, match="lookup table|keys"):
+            fresh.apply_lookup_table(cts, np.zeros(2, dtype=np.uint32))
+        fresh.generate_lookup_table(lambda x: x)
+        with pytest.raises(fhestr.FheError, match="keys"):
+            fresh.apply_lookup_table(cts, np.zeros(2, dtype=np.uint32))
+    finally:
+        fresh.close()
