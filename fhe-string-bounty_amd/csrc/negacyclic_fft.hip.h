@@ -277,6 +277,11 @@ __device__ __forceinline__ void fft_init_consts(FftConsts<PL>& c, int tau) {
     }
 }
 
+#ifdef FHESTR_NO_PIN
+#define FHE_PIN_ORDER() do {} while (0)
+#else
+#define FHE_PIN_ORDER() __builtin_amdgcn_sched_barrier(0)
+#endif
 // ---- FftSwap10 building blocks --------------------------------------------------------------
 __device__ __forceinline__ void wave_local_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -327,6 +332,24 @@ __device__ __forceinline__ int swap10_side_b(int tau, int r) {
     const int c = (l4 ^ l2) | ((l5 ^ l3) << 1) | (((r & 1) ^ l1) << 2) | (((r >> 1) ^ l0) << 3) | (l2 << 4) | (l3 << 5);
     return ((w + 4 * (lane & 3)) << 6) | c;
 }
+// Size-4 DFT (natural order) that hands every output to emit(q, y) the moment it exists, in the
+// order 0, 2, 1, 3, so stores can start while the remaining outputs are still being added up.
+template <bool INV, class Emit>
+__device__ __forceinline__ void dft4_emit(const cplx* x, Emit emit) {
+    cplx u0, u1, d0, d1, y;
+    u0.re = x[0].re + x[2].re; u0.im = x[0].im + x[2].im;
+    u1.re = x[1].re + x[3].re; u1.im = x[1].im + x[3].im;
+    d0.re = x[0].re - x[2].re; d0.im = x[0].im - x[2].im;
+    d1.re = x[1].re - x[3].re; d1.im = x[1].im - x[3].im;
+    y.re = u0.re + u1.re; y.im = u0.im + u1.im; emit(0, y);
+    y.re = u0.re - u1.re; y.im = u0.im - u1.im; emit(2, y);
+    // forward: d1 * (-i) = (d1.im, -d1.re); inverse: d1 * (+i) = (-d1.im, d1.re)
+    if (!INV) { y.re = d0.re + d1.im; y.im = d0.im - d1.re; } else { y.re = d0.re - d1.im; y.im = d0.im + d1.re; }
+    emit(1, y);
+    if (!INV) { y.re = d0.re - d1.im; y.im = d0.im + d1.re; } else { y.re = d0.re + d1.im; y.im = d0.im - d1.re; }
+    emit(3, y);
+}
+
 template <bool INV>
 __device__ __forceinline__ void swap10_twiddle(cplx* x, const cplx* tw) {
 #pragma unroll
@@ -343,9 +366,14 @@ __device__ __forceinline__ void swap10_forward(cplx (*x)[4], const FftConsts<Fft
         double* re = re0 + p * poly_stride;
         double* im = re + im_off;
         small_dft<4, false>(x[p]);
-        swap10_twiddle<false>(x[p], c.tw[0]);
+        // twiddle and store point by point: the next point's multiplies issue while the LDS write
+        // port drains the previous one
 #pragma unroll
-        for (int r = 0; r < 4; r++) { const int a = swap10_slab(tau, r); re[a] = x[p][r].re; im[a] = x[p][r].im; }
+        for (int r = 0; r < 4; r++) {
+            if (r) x[p][r] = cmul(x[p][r], c.tw[0][r]);
+            const int a = swap10_slab(tau, r); re[a] = x[p][r].re; im[a] = x[p][r].im;
+            FHE_PIN_ORDER();
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -358,9 +386,12 @@ __device__ __forceinline__ void swap10_forward(cplx (*x)[4], const FftConsts<Fft
         swap10_twiddle<false>(x[p], c.tw[1]);
         swap_regs_lanes(x[p]);
         small_dft<4, false>(x[p]);
-        swap10_twiddle<false>(x[p], c.tw[2]);
 #pragma unroll
-        for (int r = 0; r < 4; r++) { const int a = swap10_side_a(tau, r); re[a] = x[p][r].re; im[a] = x[p][r].im; }
+        for (int r = 0; r < 4; r++) {
+            if (r) x[p][r] = cmul(x[p][r], c.tw[2][r]);
+            const int a = swap10_side_a(tau, r); re[a] = x[p][r].re; im[a] = x[p][r].im;
+            FHE_PIN_ORDER();
+        }
         wave_local_fence();
 #pragma unroll
         for (int r = 0; r < 4; r++) { const int a = swap10_side_b(tau, r); x[p][r].re = re[a]; x[p][r].im = im[a]; }
@@ -380,9 +411,10 @@ __device__ __forceinline__ void swap10_inverse(cplx (*x)[4], const FftConsts<Fft
         small_dft<4, true>(x[p]);
         swap_regs_lanes(x[p]);
         swap10_twiddle<true>(x[p], c.tw[3]);
-        small_dft<4, true>(x[p]);
-#pragma unroll
-        for (int r = 0; r < 4; r++) { const int a = swap10_side_b(tau, r); re[a] = x[p][r].re; im[a] = x[p][r].im; }
+        dft4_emit<true>(x[p], [&](int r, cplx y) {
+            const int a = swap10_side_b(tau, r); re[a] = y.re; im[a] = y.im;
+            FHE_PIN_ORDER();
+        });
         wave_local_fence();
 #pragma unroll
         for (int r = 0; r < 4; r++) { const int a = swap10_side_a(tau, r); x[p][r].re = re[a]; x[p][r].im = im[a]; }
@@ -390,9 +422,10 @@ __device__ __forceinline__ void swap10_inverse(cplx (*x)[4], const FftConsts<Fft
         small_dft<4, true>(x[p]);
         swap_regs_lanes(x[p]);
         swap10_twiddle<true>(x[p], c.tw[1]);
-        small_dft<4, true>(x[p]);
-#pragma unroll
-        for (int r = 0; r < 4; r++) { const int a = swap10_comb(tau, r); re[a] = x[p][r].re; im[a] = x[p][r].im; }
+        dft4_emit<true>(x[p], [&](int r, cplx y) {
+            const int a = swap10_comb(tau, r); re[a] = y.re; im[a] = y.im;
+            FHE_PIN_ORDER();
+        });
     }
     __syncthreads();
 #pragma unroll

@@ -71,9 +71,9 @@ __device__ __forceinline__ int32_t decomp_next_digit64(uint64_t& state, uint32_t
 // (carry = bit b-1 of ((res-1) & res) = [res > B/2]).
 __device__ __forceinline__ int32_t decomp_single_digit(uint64_t x, uint32_t b) {
     const uint32_t t = (uint32_t)(x >> 32) >> (31 - b);          // b+1 top bits (b <= 31)
-    const uint32_t res = ((t + 1u) >> 1) & ((1u << b) - 1u);
-    const uint32_t carry = ((res - 1u) & res) >> (b - 1);          // [res > B/2], select-free
-    return (int32_t)(res - (carry << b));
+    const uint32_t res = __builtin_amdgcn_ubfe(t + 1u, 1u, b);     // ((t + 1) >> 1) mod B
+    const uint32_t half = 1u << (b - 1);
+    return (int32_t)(res - ((res + (half - 1u)) & (half << 1)));   // minus B iff res > B/2
 }
 // fft_impl/common.rs:26-43 (offset 0, lut_count_log 0): result in [0, 2N]
 __device__ __forceinline__ uint32_t modulus_switch(uint64_t x, int logN) {
@@ -249,7 +249,8 @@ blind_rotate_kernel(BlindRotateArgs args) {
                 const uint32_t j = tau + T * m + h * P;
                 const uint32_t src = (j - rem) & (N - 1);        // (acc*X^d)[j] = +-acc[j - rem]
                 // sign mask without selects: all-ones iff (j < rem) != odd  (j, rem < 2^31)
-                const uint64_t sm = (uint64_t)(int64_t)(int32_t)(((int32_t)(j - rem) >> 31) ^ oddmask);
+                const uint32_t sm32 = (uint32_t)(((int32_t)(j - rem) >> 31) ^ oddmask);
+                const uint64_t sm = ((uint64_t)sm32 << 32) | sm32;
                 const uint64_t v = (my_acc[src] ^ sm) - sm;
                 const uint64_t own = h == 0 ? acc_lo[m] : acc_hi[m];
                 const uint32_t st = L == 1 ? (uint32_t)decomp_single_digit(v - own, bL) : decomp_init_state(v - own, bL);
@@ -321,6 +322,7 @@ blind_rotate_kernel(BlindRotateArgs args) {
             acc_hi[m] += from_torus(t.im);
             my_acc[tau + T * m] = acc_lo[m];
             my_acc[tau + T * m + P] = acc_hi[m];
+            FHE_PIN_ORDER();      // next point's conversions overlap this point's LDS writes
         }
         __syncthreads();
     }
@@ -453,7 +455,8 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
                 for (int h = 0; h < 2; h++) {
                     const uint32_t j = tau + T * m + h * P;
                     const uint32_t src = (j - rem) & (N - 1);
-                    const uint64_t sm = (uint64_t)(int64_t)(int32_t)(((int32_t)(j - rem) >> 31) ^ oddmask);
+                    const uint32_t sm32 = (uint32_t)(((int32_t)(j - rem) >> 31) ^ oddmask);
+                const uint64_t sm = ((uint64_t)sm32 << 32) | sm32;
                     const uint64_t v = (lds_acc[(size_t)p * N + src] ^ sm) - sm;
                     const uint64_t own = h == 0 ? acc_lo[p][m] : acc_hi[p][m];
                     const uint32_t st = L == 1 ? (uint32_t)decomp_single_digit(v - own, bL) : decomp_init_state(v - own, bL);
@@ -507,6 +510,7 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
                 acc_hi[p][m] += from_torus(t.im);
                 lds_acc[(size_t)p * N + tau + T * m] = acc_lo[p][m];
                 lds_acc[(size_t)p * N + tau + T * m + P] = acc_hi[p][m];
+                FHE_PIN_ORDER();
             }
         __syncthreads();
     }
