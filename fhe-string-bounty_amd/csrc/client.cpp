@@ -4,58 +4,17 @@
 // shortint/engine/server_side.rs:54-160) and SURVEY.md section 8(f) ranks device-side key generation
 // as a later row.  Randomness: xoshiro256** seeded through splitmix64 (the reference's AES-CTR
 // CSPRNG, concrete-csprng, is out of scope); noise follows the reference's Gaussian sampler
-// (core_crypto/commons/math/random/gaussian.rs:17-47, polar method on two signed 64-bit draws).
+// (core_crypto/commons/math/random/gaussian.rs:17-47, polar method on two signed 64-bit draws) --
+// both live in det_math.h, shared with the device-side key generation kernels.
 #include <cmath>
 #include <cstring>
 #include <thread>
 #include <vector>
 
+#include "det_math.h"
 #include "engine.h"
 
 namespace fhe {
-
-struct Rng {
-    uint64_t s[4];
-    static uint64_t splitmix(uint64_t& x) {
-        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        return z ^ (z >> 31);
-    }
-    Rng(uint64_t seed, uint64_t stream) {
-        uint64_t x = seed ^ (stream * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull);
-        for (auto& v : s) v = splitmix(x);
-    }
-    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-    uint64_t next() {
-        const uint64_t result = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
-        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
-        s[2] ^= t;
-        s[3] = rotl(s[3], 45);
-        return result;
-    }
-};
-
-// core_crypto/commons/math/torus/mod.rs:72-78
-static uint64_t from_torus_host(double x) {
-    double fr = x - std::round(x);
-    fr = std::round(fr * 18446744073709551616.0);
-    if (fr >= 9223372036854775808.0) return (uint64_t)INT64_MAX;
-    if (fr <= -9223372036854775808.0) return (uint64_t)INT64_MIN;
-    return (uint64_t)(int64_t)fr;
-}
-
-static uint64_t gaussian_torus(Rng& r, double std_dev) {
-    for (;;) {
-        const double u = (double)(int64_t)r.next() * 1.0842021724855044e-19;   // 2^-63
-        const double v = (double)(int64_t)r.next() * 1.0842021724855044e-19;
-        const double s = u * u + v * v;
-        if (s > 0.0 && s < 1.0) {
-            const double cst = std_dev * std::sqrt(-2.0 * std::log(s) / s);
-            return from_torus_host(u * cst);
-        }
-    }
-}
 
 struct ClientKey {
     fhe_params_t p;

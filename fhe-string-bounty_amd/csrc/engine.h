@@ -53,6 +53,9 @@ struct Engine {
     int use();
     int set_variant(int logR);
     int load_keys(const uint64_t* bsk_std, const uint64_t* ksk);
+    int generate_keys(const uint64_t* glwe_sk, const uint64_t* small_sk, uint64_t seed,
+                      uint64_t* bsk_std_out, uint64_t* ksk_out);
+    int install_keys(uint64_t* d_ksk_std, uint64_t* d_bsk_std);
     uint64_t fill_accumulator(const uint64_t* table, std::vector<uint64_t>& acc) const { return fhe::fill_accumulator(p, table, acc); }
     int lut_upload_dedup(const std::vector<uint64_t>& acc, uint32_t* id);   // same contents -> same id
     int set_stream(hipStream_t s, bool use_own);   // launch on a caller-owned stream (e.g. the framework's current stream)

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 
+#include "keygen_kernels.hip.h"   // first: asserts fp contract(off); the FFT header turns fusion on after it
 #include "lwe_kernels.hip.h"
 #include "pbs_kernels.hip.h"
 #include "pbs_large_kernels.hip.h"
@@ -226,26 +227,82 @@ int Engine::load_keys(const uint64_t* bsk_std, const uint64_t* ksk) {
     if (use()) return 1;
     const size_t ksk_len = (size_t)p.k * p.N * p.ks_level * (p.n + 1);
     const size_t bsk_len = (size_t)p.n * p.pbs_level * (p.k + 1) * (p.k + 1) * p.N;
+    uint64_t *d_ksk_std = nullptr, *d_bsk_std = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_ksk_std, ksk_len * 8));
+    if (hipMalloc((void**)&d_bsk_std, bsk_len * 8) != hipSuccess) {
+        (void)hipFree(d_ksk_std);
+        return fail("hipMalloc of the standard-domain bootstrap key failed");
+    }
+    hipError_t e = hipMemcpyAsync(d_ksk_std, ksk, ksk_len * 8, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_bsk_std, bsk_std, bsk_len * 8, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) {
+        (void)hipFree(d_ksk_std); (void)hipFree(d_bsk_std);
+        return fail(std::string("key upload: ") + hipGetErrorString(e));
+    }
+    return install_keys(d_ksk_std, d_bsk_std);
+}
+
+// Server-key generation on the device (keygen_kernels.hip.h); replaces ServerKey::new
+// (shortint/engine/server_side.rs:54-160) for callers that hold the secret keys next to the GPU.
+int Engine::generate_keys(const uint64_t* glwe_sk, const uint64_t* small_sk, uint64_t seed,
+                          uint64_t* bsk_std_out, uint64_t* ksk_out) {
+    if (use()) return 1;
+    const size_t in_dim = (size_t)p.k * p.N;
+    const size_t ksk_len = in_dim * p.ks_level * (p.n + 1);
+    const size_t bsk_len = (size_t)p.n * p.pbs_level * (p.k + 1) * (p.k + 1) * p.N;
+    for (size_t i = 0; i < in_dim; i++)
+        if (glwe_sk[i] > 1) return fail("glwe_sk must be binary");
+    for (size_t i = 0; i < p.n; i++)
+        if (small_sk[i] > 1) return fail("small_sk must be binary");
+    uint64_t *d_gsk = nullptr, *d_ssk = nullptr, *d_ksk_std = nullptr, *d_bsk_std = nullptr;
+    auto cleanup = [&] {
+        (void)hipFree(d_gsk); (void)hipFree(d_ssk); (void)hipFree(d_ksk_std); (void)hipFree(d_bsk_std);
+    };
+    hipError_t e = hipMalloc((void**)&d_gsk, in_dim * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_ssk, (size_t)p.n * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_ksk_std, ksk_len * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_bsk_std, bsk_len * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_gsk, glwe_sk, in_dim * 8, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ssk, small_sk, (size_t)p.n * 8, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) { cleanup(); return fail(std::string("generate_keys: ") + hipGetErrorString(e)); }
+    KeygenArgs a{d_gsk, d_ssk, d_ksk_std, d_bsk_std, seed, p.n, p.k, p.N,
+                 p.pbs_base_log, p.pbs_level, p.ks_base_log, p.ks_level, p.lwe_std, p.glwe_std};
+    hipLaunchKernelGGL(ksk_gen_kernel, dim3((unsigned)((in_dim + 63) / 64)), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(bsk_gen_kernel, dim3(p.n), dim3(256), 0, stream, a);
+    e = hipGetLastError();
+    if (e == hipSuccess && ksk_out) e = hipMemcpyAsync(ksk_out, d_ksk_std, ksk_len * 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && bsk_std_out) e = hipMemcpyAsync(bsk_std_out, d_bsk_std, bsk_len * 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_gsk); d_gsk = nullptr;
+    (void)hipFree(d_ssk); d_ssk = nullptr;
+    if (e != hipSuccess) { cleanup(); return fail(std::string("generate_keys: ") + hipGetErrorString(e)); }
+    return install_keys(d_ksk_std, d_bsk_std);
+}
+
+// Takes ownership of the two standard-domain device buffers: repacks the KSK into byte planes and
+// converts the BSK to the active variant's Fourier layout, then releases them.
+int Engine::install_keys(uint64_t* d_ksk_std, uint64_t* d_std) {
+    struct Guard {
+        uint64_t*& a; uint64_t*& b;
+        ~Guard() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); }
+    } guard{d_ksk_std, d_std};
+    const size_t bsk_len = (size_t)p.n * p.pbs_level * (p.k + 1) * (p.k + 1) * p.N;
     if (d_ksk) { HIP_TRY(hipFree(d_ksk)); d_ksk = nullptr; }
     if (d_fbsk) { HIP_TRY(hipFree(d_fbsk)); d_fbsk = nullptr; }
-    HIP_TRY(hipMalloc((void**)&d_ksk, ksk_len * 8));
-    HIP_TRY(hipMemcpyAsync(d_ksk, ksk, ksk_len * 8, hipMemcpyHostToDevice, stream));
     if (d_ksk_packed) { HIP_TRY(hipFree(d_ksk_packed)); d_ksk_packed = nullptr; }
     static const bool use_dot4 = !(getenv("FHESTR_KS_MAD64") && atoi(getenv("FHESTR_KS_MAD64")));
     if (use_dot4) {   // repack into byte planes once; the 64-bit layout is then released
         const uint32_t rows = p.k * p.N * p.ks_level, osz = p.n + 1;
         HIP_TRY(hipMalloc((void**)&d_ksk_packed, (size_t)(rows / 4) * 8 * osz * 4));
         hipLaunchKernelGGL(ksk_pack_kernel, dim3((osz + 255) / 256, rows / 4), dim3(256), 0, stream,
-                           d_ksk, d_ksk_packed, rows, osz);
+                           d_ksk_std, d_ksk_packed, rows, osz);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
-        HIP_TRY(hipFree(d_ksk));
-        d_ksk = nullptr;
+    } else {
+        d_ksk = d_ksk_std;
+        d_ksk_std = nullptr;          // kept: the mad64 kernel reads the 64-bit layout
     }
-    uint64_t* d_std = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_std, bsk_len * 8));
     HIP_TRY(hipMalloc((void**)&d_fbsk, bsk_len * 8));   // N u64 -> N/2 c64: same byte count
-    HIP_TRY(hipMemcpyAsync(d_std, bsk_std, bsk_len * 8, hipMemcpyHostToDevice, stream));
     const uint32_t n_polys = (uint32_t)(bsk_len / p.N);
     const uint32_t k1 = p.k + 1;
     HIP_TRY(hipFuncSetAttribute(variant->convert_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -255,17 +312,17 @@ int Engine::load_keys(const uint64_t* bsk_std, const uint64_t* ksk) {
         void* d_cws = nullptr;
         HIP_TRY(hipMalloc(&d_cws, (size_t)blocks * variant->convert_ws));
         void* args[] = {(void*)&d_std, (void*)&d_fbsk, (void*)&n_polys, (void*)&d_cws};
-        HIP_TRY(hipLaunchKernel(variant->convert_fn, dim3(blocks), dim3(variant->convert_threads), args,
-                                variant->convert_lds, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        HIP_TRY(hipFree(d_cws));
+        hipError_t e = hipLaunchKernel(variant->convert_fn, dim3(blocks), dim3(variant->convert_threads), args,
+                                       variant->convert_lds, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(d_cws);
+        if (e != hipSuccess) return fail(std::string("bsk conversion: ") + hipGetErrorString(e));
     } else {
         void* args[] = {(void*)&d_std, (void*)&d_fbsk, (void*)&n_polys};
         HIP_TRY(hipLaunchKernel(variant->convert_fn, dim3((n_polys + k1 - 1) / k1), dim3(variant->convert_threads),
                                 args, variant->convert_lds, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     }
-    HIP_TRY(hipFree(d_std));
     HIP_TRY(hipFuncSetAttribute(variant->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(variant->lds_bytes + (size_t)p.n * 4)));
     HIP_TRY(hipFuncSetAttribute(variant_large->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -80,6 +80,9 @@ class Params:
 PARAM_MESSAGE_2_CARRY_2_KS_PBS = Params(742, 1, 2048, 23, 1, 3, 5, 4, 4,
                                         0.000007069849454709433, 0.00000000000000029403601535432533,
                                         "PARAM_MESSAGE_2_CARRY_2_KS_PBS")
+PARAM_MESSAGE_4_CARRY_4_KS_PBS = Params(996, 1, 32768, 15, 2, 3, 7, 16, 16,
+                                        6.767666038309478e-08, 2.168404344971009e-19,
+                                        "PARAM_MESSAGE_4_CARRY_4_KS_PBS")
 PARAM_MESSAGE_2_CARRY_1_KS_PBS = Params(742, 2, 1024, 23, 1, 4, 3, 4, 2,
                                         0.000007069849454709433, 0.00000000000000029403601535432533,
                                         "PARAM_MESSAGE_2_CARRY_1_KS_PBS")
@@ -91,7 +94,7 @@ _lib = None
 
 EXPORTS = [
     "fhe_last_error", "fhe_engine_create", "fhe_engine_destroy", "fhe_engine_params",
-    "fhe_engine_load_keys", "fhe_engine_stream", "fhe_engine_synchronize", "fhe_engine_set_variant",
+    "fhe_engine_load_keys", "fhe_engine_generate_keys", "fhe_engine_stream", "fhe_engine_synchronize", "fhe_engine_set_variant",
     "fhe_lut_generate", "fhe_lut_upload", "fhe_lut_download", "fhe_lut_count",
     "fhe_keyswitch_batch", "fhe_pbs_batch", "fhe_ks_pbs_batch", "fhe_ks_pbs_batch_dev", "fhe_pbs_ks_batch",
     "fhe_lwe_lincomb_batch", "fhe_last_kernel_ms", "fhe_kernel_times",
@@ -142,6 +145,7 @@ def lib() -> C.CDLL:
     sig("fhe_engine_destroy", vp)
     sig("fhe_engine_params", vp, PP)
     sig("fhe_engine_load_keys", vp, vp, vp)
+    sig("fhe_engine_generate_keys", vp, vp, vp, C.c_uint64, vp, vp)
     sig("fhe_engine_synchronize", vp)
     sig("fhe_engine_set_variant", vp, i32)
     sig("fhe_lut_generate", vp, vp, C.POINTER(u32), C.POINTER(C.c_uint64))
@@ -263,6 +267,20 @@ class Engine:
         if bsk_std.size != p.bsk_len or ksk.size != p.ksk_len:
             raise FheError("key size mismatch")
         _check(lib().fhe_engine_load_keys(self._h, _ptr(bsk_std), _ptr(ksk)))
+
+    def generate_keys(self, glwe_sk, small_sk, seed: int, export: bool = False):
+        """KSK + BSK generated on the device from the secret keys (ServerKey::new,
+        shortint/engine/server_side.rs:54-160) and installed; export=True also returns the
+        standard-domain (bsk, ksk) it generated."""
+        p = self.params
+        glwe_sk, small_sk = _u64(glwe_sk), _u64(small_sk)
+        if glwe_sk.size != p.k * p.N or small_sk.size != p.n:
+            raise FheError("secret key size mismatch")
+        bsk = np.zeros(p.bsk_len, dtype=np.uint64) if export else None
+        ksk = np.zeros(p.ksk_len, dtype=np.uint64) if export else None
+        _check(lib().fhe_engine_generate_keys(self._h, _ptr(glwe_sk), _ptr(small_sk), C.c_uint64(seed),
+                                              _ptr(bsk) if export else None, _ptr(ksk) if export else None))
+        return (bsk, ksk) if export else None
 
     # shortint/server_key/mod.rs:383-399
     def generate_lookup_table(self, f):

@@ -54,6 +54,15 @@ int fhe_engine_params(const fhe_engine *eng, fhe_params_t *out);
  * layout (replaces par_convert_standard_lwe_bootstrap_key_to_fourier,
  * core_crypto/algorithms/lwe_bootstrap_key_conversion.rs:99-152). */
 int fhe_engine_load_keys(fhe_engine *eng, const uint64_t *bsk_std, const uint64_t *ksk);
+/* Generate KSK and BSK on the device from the secret keys (k*N and n words, each 0 or 1) and install
+ * them: replaces ServerKey::new (shortint/engine/server_side.rs:54-160), i.e.
+ * allocate_and_generate_new_lwe_keyswitch_key (core_crypto/algorithms/lwe_keyswitch_key_generation.rs:65-130)
+ * and par_allocate_and_generate_new_lwe_bootstrap_key (lwe_bootstrap_key_generation.rs:237-300), followed by
+ * the Fourier conversion.  Same randomness as fhe_client_gen_server_keys: for one (secret keys, seed)
+ * the keys are bit-identical.  bsk_std_out / ksk_out (either may be NULL) receive the standard-domain
+ * keys (fhe_params_{bsk,ksk}_len words). */
+int fhe_engine_generate_keys(fhe_engine *eng, const uint64_t *glwe_sk, const uint64_t *small_sk,
+                             uint64_t seed, uint64_t *bsk_std_out, uint64_t *ksk_out);
 /* The engine's HIP stream (hipStream_t) so callers can order their own work against it. */
 void *fhe_engine_stream(fhe_engine *eng);
 /* Launch on a caller-owned hipStream_t instead (NULL = HIP's default stream), e.g. the framework

@@ -632,6 +632,39 @@ uint64_t orc_rng_next(orc_rng *r) {
     return result;
 }
 
+/* Natural logarithm of a normal, positive double from IEEE +,-,*,/ only (no libm): the noise sampler
+ * then gives the same bits on every host and on the GPU (device-side key generation is compared
+ * bit for bit against this file).  log(m * 2^e) = e ln2 + 2 atanh((m-1)/(m+1)), m in [sqrt(1/2), sqrt 2);
+ * |f| <= 0.1716, so the series through f^23 is below 2^-60 relative.  The reference calls f64::ln
+ * (gaussian.rs:33); its bits are not pinned by any test vector, only the distribution is. */
+static double det_log(double x) {
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    int e = (int)((bits >> 52) & 0x7FF) - 1023;
+    bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m;
+    memcpy(&m, &bits, 8);
+    if (m > 1.4142135623730951) {
+        m *= 0.5;
+        e += 1;
+    }
+    const double f = (m - 1.0) / (m + 1.0);
+    const double f2 = f * f;
+    double p = 1.0 / 23.0;
+    p = p * f2 + 1.0 / 21.0;
+    p = p * f2 + 1.0 / 19.0;
+    p = p * f2 + 1.0 / 17.0;
+    p = p * f2 + 1.0 / 15.0;
+    p = p * f2 + 1.0 / 13.0;
+    p = p * f2 + 1.0 / 11.0;
+    p = p * f2 + 1.0 / 9.0;
+    p = p * f2 + 1.0 / 7.0;
+    p = p * f2 + 1.0 / 5.0;
+    p = p * f2 + 1.0 / 3.0;
+    const double series = 2.0 * f + 2.0 * f * (f2 * p);
+    return (double)e * 0.6931471803691238 + (series + (double)e * 1.9082149292705877e-10);
+}
+
 /* core_crypto/commons/math/random/gaussian.rs:17-47 (Marsaglia polar method on two i64 draws) */
 void orc_rng_gaussian_pair(orc_rng *r, double std, double *a, double *b) {
     for (;;) {
@@ -639,7 +672,7 @@ void orc_rng_gaussian_pair(orc_rng *r, double std, double *a, double *b) {
         double v = (double)(int64_t)orc_rng_next(r) * 1.0842021724855044e-19;
         double s = u * u + v * v;
         if (s > 0.0 && s < 1.0) {
-            double cst = std * sqrt(-2.0 * log(s) / s);
+            double cst = std * sqrt(-2.0 * det_log(s) / s);
             *a = u * cst;
             *b = v * cst;
             return;

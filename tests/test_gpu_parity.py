@@ -361,3 +361,22 @@ def test_empty_batches_and_error_reporting(toy_k1):
             fresh.apply_lookup_table(cts, np.zeros(2, dtype=np.uint32))
     finally:
         fresh.close()
+
+
+def test_p22_device_key_generation_matches_cpu_keys(p22):
+    """fhe_engine_generate_keys on PARAM_MESSAGE_2_CARRY_2: same secret keys + seed as the CPU
+    key set => bit-identical KSK / standard BSK (the oracle's), and a working engine."""
+    import fhestr
+    from conftest import to_fhestr_params
+    eng = fhestr.Engine(to_fhestr_params(p22.params), 0)
+    try:
+        bsk, ksk = eng.generate_keys(p22.ck.glwe_sk, p22.ck.small_sk, p22.ck.seed, export=True)
+        assert np.array_equal(ksk, p22.sk.ksk.ravel())
+        assert np.array_equal(bsk, p22.sk.bsk.ravel())
+        lut_id, _ = eng.generate_lookup_table(lambda x: (x * x) % 16)
+        msgs = np.arange(64) % 16
+        cts = p22.ck.encrypt_many(msgs, O.Rng(99, 1))
+        got = eng.apply_lookup_table(cts, np.full(64, lut_id, dtype=np.uint32))
+        assert np.array_equal(p22.ck.decrypt_many(got), (msgs * msgs) % 16)
+    finally:
+        eng.close()
