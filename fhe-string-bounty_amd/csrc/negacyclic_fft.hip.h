@@ -139,6 +139,10 @@ struct FftPlan {
     static constexpr int NP = FULL + (LOGLAST ? 1 : 0);     // number of passes
     static constexpr int NTW = NP - 1;                      // passes that carry inter-pass twiddles
     __host__ __device__ static constexpr int log_radix(int s) { return s < FULL ? LOGR : LOGLAST; }
+    // complex point carried in register m of thread tau, and where coefficient j (< N = 2P) of a
+    // polynomial sits in the accumulator's LDS copy
+    __host__ __device__ static constexpr int point(int tau, int m) { return tau + T * m; }
+    __host__ __device__ static constexpr int acc_slot(int j) { return j; }   // j < N = 2P
     // log2 of sub-transform size at the start of pass s
     __host__ __device__ static constexpr int log_S(int s) { return LOGP - (s < FULL ? s : FULL) * LOGR; }
 };
@@ -148,20 +152,23 @@ struct FftPlan {
 // inter-pass exchanges never touch LDS: a 4x4 transpose between the thread's 4 registers and lane
 // bits (5,4) is two rounds of v_permlane32_swap / v_permlane16_swap (gfx950), ~8 cycles per dword on
 // the VALU against ~25 (ds_write_b64) + ~9 (ds_read_b64) per 8-byte exchange through LDS, whose
-// write port (~94 B/clk/CU) is what the CMUX loop saturates first.
+// write port (~94 B/clk/CU) is what the CMUX loop saturates first.  The one exchange that crosses
+// wavefronts comes LAST in the forward direction (first in the inverse), so in the split kernel it
+// doubles as the spectrum hand-over between the polynomial groups: every group reads the other
+// groups' points out of that exchange and runs the final butterfly on them itself.
 //
 // Index bits of point j = (b9..b0), frequency f = k0 + 4 k1 + 16 k2 + 64 k3 + 256 k4:
-//   start        regs b9b8 | wave b7b6 | lane(5,4) b5b4 | lane(3..0) b3..b0       (j = tau + 256 m)
-//   pass 1  -> k0, LDS transpose regs <-> wave        (workgroup barrier; rows of 64 slots)
-//   pass 2  -> k1, register/lane(5,4) swap
-//   pass 3  -> k2, wave-local LDS exchange            (regs b3b2, lane(5,4) b1b0, lane(3..0) k1k2)
-//   pass 4  -> k3, register/lane(5,4) swap
-//   pass 5  -> k4                                     (regs k4 | wave k0 | lane(5,4) k3 | lane(3..0) k1k2)
+//   start        regs b9b8 | lane(5,4) b7b6 | lane(3..0) b5..b2 | wave b1b0   (j = 256 m + 4 lane + wave)
+//   pass 1  -> k0, register/lane(5,4) swap
+//   pass 2  -> k1, wave-local LDS exchange        (regs b5b4, lane(5,4) b3b2, lane(3..0) k0k1)
+//   pass 3  -> k2, register/lane(5,4) swap
+//   pass 4  -> k3, LDS transpose regs <-> wave    (workgroup barrier; rows of 64 slots)
+//   pass 5  -> k4                                 (regs k4 | wave k3 | lane(5,4) k2 | lane(3..0) k0k1)
 // The inverse walks the same steps backwards.  Plane rows (64 slots each, 16 per plane): wave w owns
-// the "slab" rows 4w..4w+3 between the inverse's last read and the forward's first write, and the
-// "comb" rows {w, w+4, w+8, w+12} in between, so the only workgroup barriers are the two slab<->comb
-// transposes.  Two transforms of the same direction on the same planes need a barrier between them
-// (alternating forward/inverse, as the CMUX loop does, needs none).
+// the "slab" rows 4w..4w+3 (wave-local exchange, then its side of the transpose); the other side of
+// the transpose is the "comb" {w, w+4, w+8, w+12}.  A forward and an inverse transform may share
+// planes when every wave reads only its own comb (wide kernel); the split kernel, whose groups read
+// each other's combs, gives the inverse its own planes.
 struct FftSwap10 {
     static constexpr bool SWAP = true;
     static constexpr int LOGP = 10;
@@ -175,6 +182,10 @@ struct FftSwap10 {
     static constexpr int NTW = 4;
     __host__ __device__ static constexpr int log_radix(int) { return 2; }
     __host__ __device__ static constexpr int log_S(int s) { return 10 - 2 * s; }
+    __host__ __device__ static constexpr int point(int tau, int m) { return 256 * m + 4 * (tau & 63) + (tau >> 6); }
+    // accumulator copy (N = 2048 coefficients) stored "transposed", slot = (j mod 4) * 512 + j / 4, so
+    // that the rotation gather of a wave (coefficients 4 apart) reads consecutive slots
+    __host__ __device__ static constexpr int acc_slot(int j) { return ((j & 3) << 9) | (j >> 2); }
 };
 
 // Plan used by the blind-rotation kernels for (log2 P, log2 R).
@@ -265,7 +276,10 @@ __device__ __forceinline__ void fft_init_consts(FftConsts<PL>& c, int tau) {
         const int lS = PL::log_S(s);
         const int lS1 = lS - PL::LOGR;
         int tp = tau & ((1 << lS1) - 1);
-        if (PL::SWAP && s == 3) tp = (tau >> 4) & 3;     // pass 4 runs with b1b0 in lane bits (5,4)
+        if (PL::SWAP) {   // low index bits still to be transformed after pass s (see FftSwap10)
+            const int lane = tau & 63, w = tau >> 6;
+            tp = s == 0 ? ((lane << 2) | w) : s == 1 ? (((lane & 15) << 2) | w) : s == 2 ? (((lane >> 4) << 2) | w) : w;
+        }
 #pragma unroll
         for (int q = 0; q < PL::R; q++) {
             double sn, cs;
@@ -312,25 +326,26 @@ __device__ __forceinline__ void swap_regs_lanes(cplx* x) {
     swap_halves<true>(x[0].re, x[1].re);  swap_halves<true>(x[0].im, x[1].im);
     swap_halves<true>(x[2].re, x[3].re);  swap_halves<true>(x[2].im, x[3].im);
 }
-// slab <-> comb transposes (regs <-> wave).  Slot = row * 64 + lane: conflict free as is.
+// slab <-> comb transpose (regs <-> wave).  Slot = row * 64 + lane: conflict free as is.
 __device__ __forceinline__ int swap10_slab(int tau, int r) { return (((tau >> 6) * 4 + r) << 6) | (tau & 63); }
 __device__ __forceinline__ int swap10_comb(int tau, int r) { return ((r * 4 + (tau >> 6)) << 6) | (tau & 63); }
-// Wave-local exchange inside the wave's comb rows.  Side A: regs k2 | lane(5,4) k1 | lane(3..0) b3..b0;
-// side B: regs b3b2 | lane(5,4) b1b0 | lane(3..0) k1hi k1lo k2hi k2lo.  Slot within the 4 comb rows:
-//   c0 = b0^k1lo  c1 = b1^k1hi  c2 = b2^k2hi  c3 = b3^k2lo  c4 = k1lo  c5 = k1hi  row = k2
+// Wave-local exchange inside the wave's slab rows.  Side A: regs k1 | lane(5,4) k0 | lane(3..0) b5..b2;
+// side B: regs b5b4 | lane(5,4) b3b2 | lane(3..0) k0hi k0lo k1hi k1lo.  With (u3..u0) = b5..b2, slot
+// within the 4 slab rows:
+//   c0 = u0^k0lo  c1 = u1^k0hi  c2 = u2^k1hi  c3 = u3^k1lo  c4 = k0lo  c5 = k0hi  row = k1
 // -- every 16-lane group of either side covers 16 distinct slots mod 16 and every 32-lane group 32
 // distinct slots mod 32 (the ds_write_b64 / ds_read_b64 conflict-free conditions).
 __device__ __forceinline__ int swap10_side_a(int tau, int r) {
     const int lane = tau & 63, w = tau >> 6;
     const int c = lane ^ ((lane >> 4) & 1) ^ (((lane >> 5) & 1) << 1) ^ ((r >> 1) << 2) ^ ((r & 1) << 3);
-    return ((w + 4 * r) << 6) | c;
+    return ((4 * w + r) << 6) | c;
 }
 __device__ __forceinline__ int swap10_side_b(int tau, int r) {
     const int lane = tau & 63, w = tau >> 6;
     const int l0 = lane & 1, l1 = (lane >> 1) & 1, l2 = (lane >> 2) & 1, l3 = (lane >> 3) & 1;
     const int l4 = (lane >> 4) & 1, l5 = (lane >> 5) & 1;
     const int c = (l4 ^ l2) | ((l5 ^ l3) << 1) | (((r & 1) ^ l1) << 2) | (((r >> 1) ^ l0) << 3) | (l2 << 4) | (l3 << 5);
-    return ((w + 4 * (lane & 3)) << 6) | c;
+    return ((4 * w + (lane & 3)) << 6) | c;
 }
 // Size-4 DFT (natural order) that hands every output to emit(q, y) the moment it exists, in the
 // order 0, 2, 1, 3, so stores can start while the remaining outputs are still being added up.
@@ -349,11 +364,75 @@ __device__ __forceinline__ void dft4_emit(const cplx* x, Emit emit) {
     if (!INV) { y.re = d0.re - d1.im; y.im = d0.im + d1.re; } else { y.re = d0.re + d1.im; y.im = d0.im - d1.re; }
     emit(3, y);
 }
-
 template <bool INV>
 __device__ __forceinline__ void swap10_twiddle(cplx* x, const cplx* tw) {
 #pragma unroll
     for (int q = 1; q < 4; q++) x[q] = INV ? cmul_conj(x[q], tw[q]) : cmul(x[q], tw[q]);
+}
+
+// Forward transform in two halves around its one workgroup barrier.
+//   head: passes 1-4 of this thread's polynomial, left in the slab side of the (re, im) planes
+//   tail: after the barrier, the comb side of ANY polynomial's planes -> last pass -> x[rho]
+__device__ __forceinline__ void swap10_forward_head(cplx* x, const FftConsts<FftSwap10>& c, double* re, double* im, int tau) {
+    small_dft<4, false>(x);
+    swap10_twiddle<false>(x, c.tw[0]);
+    swap_regs_lanes(x);
+    small_dft<4, false>(x);
+    // twiddle and store point by point: the next point's multiplies issue while the LDS write port
+    // drains the previous one
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (r) x[r] = cmul(x[r], c.tw[1][r]);
+        const int a = swap10_side_a(tau, r); re[a] = x[r].re; im[a] = x[r].im;
+        FHE_PIN_ORDER();
+    }
+    wave_local_fence();
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int a = swap10_side_b(tau, r); x[r].re = re[a]; x[r].im = im[a]; }
+    small_dft<4, false>(x);
+    swap10_twiddle<false>(x, c.tw[2]);
+    swap_regs_lanes(x);
+    small_dft<4, false>(x);
+    wave_local_fence();          // the slab stores below reuse the rows the exchange above read
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (r) x[r] = cmul(x[r], c.tw[3][r]);
+        const int a = swap10_slab(tau, r); re[a] = x[r].re; im[a] = x[r].im;
+        FHE_PIN_ORDER();
+    }
+}
+__device__ __forceinline__ void swap10_forward_tail(cplx* x, const double* re, const double* im, int tau) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int a = swap10_comb(tau, r); x[r].re = re[a]; x[r].im = im[a]; }
+    small_dft<4, false>(x);
+}
+// Inverse: head = first pass + comb stores; barrier; tail = slab loads + the remaining passes.
+__device__ __forceinline__ void swap10_inverse_head(const cplx* x, double* re, double* im, int tau) {
+    dft4_emit<true>(x, [&](int r, cplx y) {
+        const int a = swap10_comb(tau, r); re[a] = y.re; im[a] = y.im;
+        FHE_PIN_ORDER();
+    });
+}
+__device__ __forceinline__ void swap10_inverse_tail(cplx* x, const FftConsts<FftSwap10>& c, double* re, double* im, int tau) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int a = swap10_slab(tau, r); x[r].re = re[a]; x[r].im = im[a]; }
+    swap10_twiddle<true>(x, c.tw[3]);
+    small_dft<4, true>(x);
+    swap_regs_lanes(x);
+    swap10_twiddle<true>(x, c.tw[2]);
+    wave_local_fence();          // the exchange below reuses the slab rows just read
+    dft4_emit<true>(x, [&](int r, cplx y) {
+        const int a = swap10_side_b(tau, r); re[a] = y.re; im[a] = y.im;
+        FHE_PIN_ORDER();
+    });
+    wave_local_fence();
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int a = swap10_side_a(tau, r); x[r].re = re[a]; x[r].im = im[a]; }
+    swap10_twiddle<true>(x, c.tw[1]);
+    small_dft<4, true>(x);
+    swap_regs_lanes(x);
+    swap10_twiddle<true>(x, c.tw[0]);
+    small_dft<4, true>(x);
 }
 
 // NPOLY polynomials carried by the same threads (planes of polynomial p at re0 + p*poly_stride,
@@ -362,81 +441,19 @@ template <int NPOLY>
 __device__ __forceinline__ void swap10_forward(cplx (*x)[4], const FftConsts<FftSwap10>& c, double* re0,
                                                int poly_stride, int im_off, int tau) {
 #pragma unroll
-    for (int p = 0; p < NPOLY; p++) {
-        double* re = re0 + p * poly_stride;
-        double* im = re + im_off;
-        small_dft<4, false>(x[p]);
-        // twiddle and store point by point: the next point's multiplies issue while the LDS write
-        // port drains the previous one
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            if (r) x[p][r] = cmul(x[p][r], c.tw[0][r]);
-            const int a = swap10_slab(tau, r); re[a] = x[p][r].re; im[a] = x[p][r].im;
-            FHE_PIN_ORDER();
-        }
-    }
+    for (int p = 0; p < NPOLY; p++) swap10_forward_head(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < NPOLY; p++) {
-        double* re = re0 + p * poly_stride;
-        double* im = re + im_off;
-#pragma unroll
-        for (int r = 0; r < 4; r++) { const int a = swap10_comb(tau, r); x[p][r].re = re[a]; x[p][r].im = im[a]; }
-        small_dft<4, false>(x[p]);
-        swap10_twiddle<false>(x[p], c.tw[1]);
-        swap_regs_lanes(x[p]);
-        small_dft<4, false>(x[p]);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            if (r) x[p][r] = cmul(x[p][r], c.tw[2][r]);
-            const int a = swap10_side_a(tau, r); re[a] = x[p][r].re; im[a] = x[p][r].im;
-            FHE_PIN_ORDER();
-        }
-        wave_local_fence();
-#pragma unroll
-        for (int r = 0; r < 4; r++) { const int a = swap10_side_b(tau, r); x[p][r].re = re[a]; x[p][r].im = im[a]; }
-        small_dft<4, false>(x[p]);
-        swap10_twiddle<false>(x[p], c.tw[3]);
-        swap_regs_lanes(x[p]);
-        small_dft<4, false>(x[p]);
-    }
+    for (int p = 0; p < NPOLY; p++) swap10_forward_tail(x[p], re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
 }
 template <int NPOLY>
 __device__ __forceinline__ void swap10_inverse(cplx (*x)[4], const FftConsts<FftSwap10>& c, double* re0,
                                                int poly_stride, int im_off, int tau) {
 #pragma unroll
-    for (int p = 0; p < NPOLY; p++) {
-        double* re = re0 + p * poly_stride;
-        double* im = re + im_off;
-        small_dft<4, true>(x[p]);
-        swap_regs_lanes(x[p]);
-        swap10_twiddle<true>(x[p], c.tw[3]);
-        dft4_emit<true>(x[p], [&](int r, cplx y) {
-            const int a = swap10_side_b(tau, r); re[a] = y.re; im[a] = y.im;
-            FHE_PIN_ORDER();
-        });
-        wave_local_fence();
-#pragma unroll
-        for (int r = 0; r < 4; r++) { const int a = swap10_side_a(tau, r); x[p][r].re = re[a]; x[p][r].im = im[a]; }
-        swap10_twiddle<true>(x[p], c.tw[2]);
-        small_dft<4, true>(x[p]);
-        swap_regs_lanes(x[p]);
-        swap10_twiddle<true>(x[p], c.tw[1]);
-        dft4_emit<true>(x[p], [&](int r, cplx y) {
-            const int a = swap10_comb(tau, r); re[a] = y.re; im[a] = y.im;
-            FHE_PIN_ORDER();
-        });
-    }
+    for (int p = 0; p < NPOLY; p++) swap10_inverse_head(x[p], re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < NPOLY; p++) {
-        double* re = re0 + p * poly_stride;
-        double* im = re + im_off;
-#pragma unroll
-        for (int r = 0; r < 4; r++) { const int a = swap10_slab(tau, r); x[p][r].re = re[a]; x[p][r].im = im[a]; }
-        swap10_twiddle<true>(x[p], c.tw[0]);
-        small_dft<4, true>(x[p]);
-    }
+    for (int p = 0; p < NPOLY; p++) swap10_inverse_tail(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
 }
 
 // Forward transform.  In: x[m] = point (tau + T*m) of the (already twisted) input.

@@ -81,6 +81,48 @@ __device__ __forceinline__ uint32_t modulus_switch(uint64_t x, int logN) {
     return (uint32_t)((o + 1) >> 1);
 }
 
+// LDS slot of coefficient j (< N) inside one polynomial's accumulator copy
+template <class PL>
+__device__ __forceinline__ uint32_t acc_slot_of(uint32_t j) { return (uint32_t)PL::acc_slot((int)j); }
+
+// Monomial rotation bookkeeping of one CMUX step: for the coefficient j = PL::point(tau, m) + h*P this
+// thread owns, where (acc * X^d)[j] = +-acc[(j - rem) mod N] sits in the LDS copy and whether it is
+// negated (polynomial_algorithms.rs:463-489; d = odd * N + rem).  The swap plan's thread owns
+// j = 4 q' + w (w = wave index) and stores coefficient 4 q + r at slot r * N/4 + q, so j - rem =
+// 4 (q' - rem/4 - [w < rem%4]) + ((w - rem) mod 4): everything but one add and one and-or per
+// coefficient is per-step or compile-time.
+template <class PL, int LOGN>
+struct Rotation {
+    int32_t oddmask;
+    uint32_t rem;        // generic plans
+    int32_t qb;          // swap plan: lane - rem/4 - borrow
+    uint32_t rbits;      // swap plan: ((w - rem) mod 4) << (LOGN - 2)
+    __device__ __forceinline__ Rotation(uint32_t d, int tau) {
+        rem = d & ((1u << LOGN) - 1);
+        oddmask = -(int32_t)((d >> LOGN) & 1);
+        if constexpr (PL::SWAP) {
+            const int w = tau >> 6, lane = tau & 63;
+            const int rr = (int)(rem & 3);
+            qb = lane - (int)(rem >> 2) - (w < rr ? 1 : 0);
+            rbits = (uint32_t)((w - rr) & 3) << (LOGN - 2);
+        } else {
+            qb = 0; rbits = 0;
+        }
+    }
+    // slot of the source coefficient and its all-ones / all-zero negation mask
+    __device__ __forceinline__ void source(int tau, int m, int h, uint32_t& slot, uint32_t& neg) const {
+        if constexpr (PL::SWAP) {
+            const int32_t q = qb + (PL::point(0, m) + h * PL::P) / 4;
+            neg = (uint32_t)((q >> 31) ^ oddmask);
+            slot = rbits | ((uint32_t)q & ((1u << (LOGN - 2)) - 1));
+        } else {
+            const uint32_t j = (uint32_t)PL::point(tau, m) + (uint32_t)h * PL::P;
+            neg = (uint32_t)(((int32_t)(j - rem) >> 31) ^ oddmask);   // j, rem < 2^31
+            slot = acc_slot_of<PL>((j - rem) & ((1u << LOGN) - 1));
+        }
+    }
+};
+
 template <int LOGN, int LOGR, int K1, int L>
 struct BrCfg {
     static constexpr int N = 1 << LOGN;
@@ -118,7 +160,7 @@ bsk_convert_kernel(const uint64_t* __restrict__ bsk_std, double* __restrict__ fb
     cplx x[R];
 #pragma unroll
     for (int m = 0; m < R; m++) {
-        const int j = tau + T * m;
+        const int j = PL::point(tau, m);
         uint64_t a = active ? bsk_std[(size_t)poly * N + j] : 0;
         uint64_t b = active ? bsk_std[(size_t)poly * N + j + P] : 0;
         // forward_as_torus: signed value * 2^-64 (fft/mod.rs:197-218)
@@ -185,12 +227,12 @@ blind_rotate_kernel(BlindRotateArgs args) {
 #pragma unroll
     for (int m = 0; m < R; m++) {
         double sn, cs;
-        sincospi((double)(tau + T * m) / (double)N, &sn, &cs);
+        sincospi((double)PL::point(tau, m) / (double)N, &sn, &cs);
         twist[m].re = cs; twist[m].im = sn;
     }
 
     // acc <- LUT * X^{-ms(body)}   (bootstrap.rs:254-271, polynomial_algorithms.rs:331-353)
-    uint64_t acc_lo[R], acc_hi[R];   // coefficients j = tau + T*m and j + P
+    uint64_t acc_lo[R], acc_hi[R];   // coefficients j = PL::point(tau, m) and j + P
     {
         const uint32_t d = modulus_switch(lwe[n], LOGN);
         const uint32_t rem = d & (N - 1);
@@ -199,7 +241,7 @@ blind_rotate_kernel(BlindRotateArgs args) {
         for (int m = 0; m < R; m++) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const uint32_t j = tau + T * m + h * P;
+                const uint32_t j = PL::point(tau, m) + h * P;
                 const uint32_t src = (j + rem) & (N - 1);       // out[j] = +-in[j + rem]
                 const bool neg = ((j + rem) >= (uint32_t)N) != odd;
                 uint64_t v = lut[(size_t)g * N + src];
@@ -210,8 +252,8 @@ blind_rotate_kernel(BlindRotateArgs args) {
     }
 #pragma unroll
     for (int m = 0; m < R; m++) {
-        my_acc[tau + T * m] = acc_lo[m];
-        my_acc[tau + T * m + P] = acc_hi[m];
+        my_acc[acc_slot_of<PL>(PL::point(tau, m))] = acc_lo[m];
+        my_acc[acc_slot_of<PL>(PL::point(tau, m) + P)] = acc_hi[m];
     }
     __syncthreads();
 
@@ -223,8 +265,7 @@ blind_rotate_kernel(BlindRotateArgs args) {
         const uint32_t d = d_next;
         d_next = lds_d[i + 1 < n ? i + 1 : i];                  // prefetch (LDS broadcast read)
         if (d == 0xFFFFFFFFu) continue;                          // block-uniform
-        const uint32_t rem = d & (N - 1);
-        const int32_t oddmask = -(int32_t)((d >> LOGN) & 1);
+        const Rotation<PL, LOGN> rot(d, tau);
 
         // Fourier GGSW rows of the last decomposition level handled first (ggsw.rs:524): issue the
         // global loads now, they land while the forward FFT runs (L2 / Infinity-Cache resident key)
@@ -246,12 +287,10 @@ blind_rotate_kernel(BlindRotateArgs args) {
         for (int m = 0; m < R; m++) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const uint32_t j = tau + T * m + h * P;
-                const uint32_t src = (j - rem) & (N - 1);        // (acc*X^d)[j] = +-acc[j - rem]
-                // sign mask without selects: all-ones iff (j < rem) != odd  (j, rem < 2^31)
-                const uint32_t sm32 = (uint32_t)(((int32_t)(j - rem) >> 31) ^ oddmask);
+                uint32_t slot, sm32;                             // (acc*X^d)[j] = +-acc[j - rem], select-free
+                rot.source(tau, m, h, slot, sm32);
                 const uint64_t sm = ((uint64_t)sm32 << 32) | sm32;
-                const uint64_t v = (my_acc[src] ^ sm) - sm;
+                const uint64_t v = (my_acc[slot] ^ sm) - sm;
                 const uint64_t own = h == 0 ? acc_lo[m] : acc_hi[m];
                 const uint32_t st = L == 1 ? (uint32_t)decomp_single_digit(v - own, bL) : decomp_init_state(v - own, bL);
                 if (h == 0) st_lo[m] = st; else st_hi[m] = st;
@@ -259,6 +298,51 @@ blind_rotate_kernel(BlindRotateArgs args) {
         }
 
         cplx outf[R];
+        if constexpr (PL::SWAP) {
+            // Swap plan (single level): the forward transform's only workgroup barrier is also the
+            // spectrum hand-over -- after it every group runs the last radix-4 pass on its own AND
+            // on the other groups' points, so no spectrum is ever written back to LDS.
+            static_assert(!PL::SWAP || L == 1, "swap plan: single decomposition level only");
+            cplx x[K1][R];
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                cplx z;
+                z.re = (double)(int32_t)st_lo[m];
+                z.im = (double)(int32_t)st_hi[m];
+                x[0][m] = cmul(z, twist[m]);                     // fft/mod.rs:220-239
+            }
+            swap10_forward_head(x[0], fc, xre, xim, tau);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < K1; r++) {
+                const int row = (g + r) % K1;                    // r = 0: own polynomial
+                const double* rre = lds_x + (size_t)row * CFG::GROUP_SLOTS;
+                swap10_forward_tail(x[r], rre, rre + CFG::PLANE, tau);
+            }
+            // outf[col = g] = sum_row FBSK[i][0][row][g] * F[row]   (ggsw.rs:616-697)
+#pragma unroll
+            for (int r = 0; r < K1; r++) {
+#pragma unroll
+                for (int rho = 0; rho < R; rho++) {
+                    const double2 bv = bpre[r][rho];
+                    const cplx f = x[r][rho];
+                    if (r == 0) {
+                        outf[rho].re = bv.x * f.re - bv.y * f.im;
+                        outf[rho].im = bv.x * f.im + bv.y * f.re;
+                    } else {
+                        outf[rho].re = fma(bv.x, f.re, fma(-bv.y, f.im, outf[rho].re));
+                        outf[rho].im = fma(bv.x, f.im, fma(bv.y, f.re, outf[rho].im));
+                    }
+                }
+            }
+            // inverse on its own planes (lds_f): other groups may still be reading this group's
+            // forward planes
+            double* fre = lds_f + (size_t)g * CFG::GROUP_SLOTS;
+            double* fim = fre + CFG::PLANE;
+            swap10_inverse_head(outf, fre, fim, tau);
+            __syncthreads();
+            swap10_inverse_tail(outf, fc, fre, fim, tau);
+        } else {
 #pragma unroll
         for (int it = 0; it < L; it++) {
             const int lvl_idx = L - 1 - it;                      // ggsw.rs:524 (levels reversed)
@@ -314,14 +398,15 @@ blind_rotate_kernel(BlindRotateArgs args) {
         // back to the standard domain and accumulate (fft/mod.rs:285-304, 539-557); the 1/(N/2)
         // normalisation lives in the Fourier key (bsk_convert_kernel)
         fft_inverse<PL>(outf, fc, xre, xim, tau);
+        }
         // every gather of this step's my_acc happened several barriers ago: safe to overwrite
 #pragma unroll
         for (int m = 0; m < R; m++) {
             cplx t = cmul_conj(outf[m], twist[m]);
             acc_lo[m] += from_torus(t.re);
             acc_hi[m] += from_torus(t.im);
-            my_acc[tau + T * m] = acc_lo[m];
-            my_acc[tau + T * m + P] = acc_hi[m];
+            my_acc[acc_slot_of<PL>(PL::point(tau, m))] = acc_lo[m];
+            my_acc[acc_slot_of<PL>(PL::point(tau, m) + P)] = acc_hi[m];
             FHE_PIN_ORDER();      // next point's conversions overlap this point's LDS writes
         }
         __syncthreads();
@@ -333,7 +418,7 @@ blind_rotate_kernel(BlindRotateArgs args) {
     for (int m = 0; m < R; m++) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const uint32_t j = tau + T * m + h * P;
+            const uint32_t j = PL::point(tau, m) + h * P;
             const uint64_t v = h == 0 ? acc_lo[m] : acc_hi[m];
             if (g == K1 - 1) {
                 if (j == 0) out[(size_t)(K1 - 1) * N] = v;         // body = B[0]
@@ -396,7 +481,7 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
 #pragma unroll
     for (int m = 0; m < R; m++) {
         double sn, cs;
-        sincospi((double)(tau + T * m) / (double)N, &sn, &cs);
+        sincospi((double)PL::point(tau, m) / (double)N, &sn, &cs);
         twist[m].re = cs; twist[m].im = sn;
     }
 
@@ -411,13 +496,13 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
             for (int m = 0; m < R; m++)
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const uint32_t j = tau + T * m + h * P;
+                    const uint32_t j = PL::point(tau, m) + h * P;
                     const uint32_t src = (j + rem) & (N - 1);
                     const bool neg = ((j + rem) >= (uint32_t)N) != odd;
                     uint64_t v = lut[(size_t)p * N + src];
                     v = neg ? (0 - v) : v;
                     if (h == 0) acc_lo[p][m] = v; else acc_hi[p][m] = v;
-                    lds_acc[(size_t)p * N + j] = v;
+                    lds_acc[(size_t)p * N + acc_slot_of<PL>(j)] = v;
                 }
     }
     __syncthreads();
@@ -430,8 +515,7 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
         const uint32_t d = d_next;
         d_next = lds_d[i + 1 < n ? i + 1 : i];
         if (d == 0xFFFFFFFFu) continue;
-        const uint32_t rem = d & (N - 1);
-        const int32_t oddmask = -(int32_t)((d >> LOGN) & 1);
+        const Rotation<PL, LOGN> rot(d, tau);
         const double2* bk0 = fbsk + (size_t)i * GGSW_ELEMS;
 
         double2 bpre[CFG::PREFETCH_ALL ? K1 : 1][CFG::PREFETCH_ALL ? K1 : 1][R];
@@ -453,11 +537,10 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
             for (int m = 0; m < R; m++)
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const uint32_t j = tau + T * m + h * P;
-                    const uint32_t src = (j - rem) & (N - 1);
-                    const uint32_t sm32 = (uint32_t)(((int32_t)(j - rem) >> 31) ^ oddmask);
-                const uint64_t sm = ((uint64_t)sm32 << 32) | sm32;
-                    const uint64_t v = (lds_acc[(size_t)p * N + src] ^ sm) - sm;
+                    uint32_t slot, sm32;
+                    rot.source(tau, m, h, slot, sm32);
+                    const uint64_t sm = ((uint64_t)sm32 << 32) | sm32;
+                    const uint64_t v = (lds_acc[(size_t)p * N + slot] ^ sm) - sm;
                     const uint64_t own = h == 0 ? acc_lo[p][m] : acc_hi[p][m];
                     const uint32_t st = L == 1 ? (uint32_t)decomp_single_digit(v - own, bL) : decomp_init_state(v - own, bL);
                     if (h == 0) st_lo[p][m] = st; else st_hi[p][m] = st;
@@ -508,8 +591,8 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
                 cplx t = cmul_conj(outf[p][m], twist[m]);
                 acc_lo[p][m] += from_torus(t.re);
                 acc_hi[p][m] += from_torus(t.im);
-                lds_acc[(size_t)p * N + tau + T * m] = acc_lo[p][m];
-                lds_acc[(size_t)p * N + tau + T * m + P] = acc_hi[p][m];
+                lds_acc[(size_t)p * N + acc_slot_of<PL>(PL::point(tau, m))] = acc_lo[p][m];
+                lds_acc[(size_t)p * N + acc_slot_of<PL>(PL::point(tau, m) + P)] = acc_hi[p][m];
                 FHE_PIN_ORDER();
             }
         __syncthreads();
@@ -522,7 +605,7 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
         for (int m = 0; m < R; m++)
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const uint32_t j = tau + T * m + h * P;
+                const uint32_t j = PL::point(tau, m) + h * P;
                 const uint64_t v = h == 0 ? acc_lo[p][m] : acc_hi[p][m];
                 if (p == K1 - 1) {
                     if (j == 0) out[(size_t)(K1 - 1) * N] = v;
