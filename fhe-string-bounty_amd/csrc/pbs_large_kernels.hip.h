@@ -48,6 +48,19 @@ struct BrLargeCfg {
     static constexpr size_t WS_TMP = (size_t)L * K1 * P * 16;
     static constexpr size_t WS_TMP2 = (size_t)K1 * P * 16;
     static constexpr size_t WS_BYTES = WS_ACC + WS_TMP + WS_TMP2;
+    // Workspace arrays are P1 x P2 matrices (row = column-transform index, col = row-transform index)
+    // stored in column tiles of width W = the number of columns one workgroup iteration transforms:
+    // [col / W][row][col % W].  A column iteration then touches one dense P1*W tile (instead of
+    // P1 chunks of W elements a whole matrix row apart) and a row still reads W-element runs, so
+    // DRAM pages are opened once per iteration rather than once per P2/W iterations.
+    static constexpr int LOGW = ilog2c(SUBS_A < P2 ? SUBS_A : P2);
+    __host__ __device__ static constexpr size_t tix(int row, int col) {
+        return ((size_t)(col >> LOGW) << (LOGP1 + LOGW)) | ((size_t)row << LOGW) | (size_t)(col & ((1 << LOGW) - 1));
+    }
+    // coefficient j (< N) of an accumulator polynomial: halves [0,P) and [P,N) tiled separately
+    __host__ __device__ static constexpr size_t aix(uint32_t j) {
+        return (size_t)(j & ~(uint32_t)(P - 1)) + tix((int)((j & (P - 1)) >> LOGP2), (int)(j & (P2 - 1)));
+    }
 };
 
 // frequency index of the value an in-place DIF transform leaves at last-pass address A
@@ -122,7 +135,7 @@ __device__ __forceinline__ void column_forward_store(cplx* x, const FftConsts<ty
         const int q1 = freq_of_addr<PA>(A);
         const cplx w = roots.get(0u - 4u * (uint32_t)(q1 * b));     // e^{-2 pi i q1 b / P}, 1/P = 4/(2N)
         const cplx v = cmul(x[rho], w);
-        dst[(size_t)A * CFG::P2 + b] = make_double2(v.re, v.im);
+        dst[CFG::tix(A, b)] = make_double2(v.re, v.im);
     }
 }
 
@@ -171,7 +184,7 @@ bsk_convert_large_kernel(const uint64_t* __restrict__ bsk_std, double* __restric
             cplx x[R];
 #pragma unroll
             for (int m = 0; m < R; m++) {
-                const double2 v = tmp[(size_t)r * P2 + tauB + CFG::TB * m];
+                const double2 v = tmp[CFG::tix(r, tauB + CFG::TB * m)];
                 x[m].re = v.x; x[m].im = v.y;
             }
             fft_forward<PB>(x, fcb, lds + (size_t)subB * CFG::SLOTS_B, lds + (size_t)subB * CFG::SLOTS_B + P2 + 2, tauB);
@@ -234,7 +247,7 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
             const uint32_t src = (j + rem) & (N - 1);
             const bool neg = ((j + rem) >= (uint32_t)N) != odd;
             const uint64_t v = lut[(size_t)p * N + src];
-            acc[e] = neg ? (0 - v) : v;
+            acc[(size_t)p * N + CFG::aix(j)] = neg ? (0 - v) : v;
         }
     }
     __syncthreads();
@@ -268,11 +281,12 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
                         const uint32_t j = (tauA + CFG::TA * m) * P2 + b + h * P;
                         const uint32_t src = (j - rem) & (N - 1);
                         const bool neg = (j < rem) != odd;
-                        uint64_t v = ap[src];
+                        uint64_t v = ap[CFG::aix(src)];
                         v = neg ? (0 - v) : v;
+                        const uint64_t own = ap[CFG::aix(j)];
                         state_t st;
-                        if constexpr (L >= 3) st = decomp_init_state64(v - ap[j], bL);
-                        else st = decomp_init_state(v - ap[j], bL);
+                        if constexpr (L >= 3) st = decomp_init_state64(v - own, bL);
+                        else st = decomp_init_state(v - own, bL);
                         if (h == 0) st_lo[m] = st; else st_hi[m] = st;
                     }
                 }
@@ -309,10 +323,10 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
 #pragma unroll
                 for (int row = 0; row < K1; row++) {
                     cplx x[R];
-                    const double2* srow = tmp + (size_t)(it * K1 + row) * P + (size_t)r * P2;
+                    const double2* spoly = tmp + (size_t)(it * K1 + row) * P;
 #pragma unroll
                     for (int m = 0; m < R; m++) {
-                        const double2 v = srow[tauB + CFG::TB * m];
+                        const double2 v = spoly[CFG::tix(r, tauB + CFG::TB * m)];
                         x[m].re = v.x; x[m].im = v.y;
                     }
                     fft_forward<PB>(x, fcb, breB, bimB, tauB);
@@ -337,13 +351,13 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
 #pragma unroll
             for (int col = 0; col < K1; col++) {
                 fft_inverse<PB>(outf[col], fcb, breB, bimB, tauB);
-                double2* drow = tmp2 + (size_t)col * P + (size_t)r * P2;
+                double2* dpoly = tmp2 + (size_t)col * P;
 #pragma unroll
                 for (int m = 0; m < R; m++) {
                     const int b = tauB + CFG::TB * m;
                     const cplx w = roots.get(4u * (uint32_t)(q1 * b));   // conj of the forward twiddle
                     const cplx v = cmul(outf[col][m], w);
-                    drow[b] = make_double2(v.re, v.im);
+                    dpoly[CFG::tix(r, b)] = make_double2(v.re, v.im);
                 }
             }
         }
@@ -358,7 +372,7 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
                 cplx x[R];
 #pragma unroll
                 for (int rho = 0; rho < R; rho++) {
-                    const double2 v = sp[(size_t)slot_addr<PA>(tauA, rho) * P2 + b];
+                    const double2 v = sp[CFG::tix(slot_addr<PA>(tauA, rho), b)];
                     x[rho].re = v.x; x[rho].im = v.y;
                 }
                 fft_inverse<PA>(x, fca, areA, aimA, tauA);
@@ -366,8 +380,9 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
                 for (int m = 0; m < R; m++) {
                     const int j = (tauA + CFG::TA * m) * P2 + b;
                     const cplx t = cmul_conj(x[m], roots.get((uint32_t)j));
-                    ap[j] += from_torus(t.re);
-                    ap[j + P] += from_torus(t.im);
+                    const size_t ja = CFG::aix((uint32_t)j);
+                    ap[ja] += from_torus(t.re);
+                    ap[ja + P] += from_torus(t.im);
                 }
             }
         }
@@ -378,7 +393,7 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
     uint64_t* out = args.lwe_out + (size_t)sample * ((size_t)(K1 - 1) * N + 1);
     for (int e = tid; e < K1 * N; e += NT) {
         const uint32_t p = e >> LOGN, j = e & (N - 1);
-        const uint64_t v = acc[e];
+        const uint64_t v = acc[(size_t)p * N + CFG::aix(j)];
         if (p == K1 - 1) {
             if (j == 0) out[(size_t)(K1 - 1) * N] = v;
         } else {
