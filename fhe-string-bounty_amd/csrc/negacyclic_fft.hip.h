@@ -222,6 +222,12 @@ FHE_SWZ(9, 2, 5, 24, 2, 6, 17, 11, 16, 2, 2, 0, 0, 0, 0, 0, 0, 0)
 FHE_SWZ(8, 2, 10, 1, 25, 4, 12, 3, 16, 8, 0, 0, 0, 0, 0, 0, 0, 0)
 FHE_SWZ(7, 2, 2, 4, 10, 25, 1, 5, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0)
 FHE_SWZ(11, 2, 18, 28, 9, 10, 1, 4, 16, 4, 8, 2, 9, 0, 0, 0, 0, 0)
+// 128 points, 8 per thread, 16 threads per transform, transforms 16 slots (mod 32) apart -- the
+// large-N kernels' sub-transforms.  Derived by hand: the three pass layouts leave address bits
+// {0,1,2,3}, {0,4,5,6} and {3,4,5,6} free across the 16 lanes of a transform; the low four slot bits
+// (a0^a6, a1^a4, a2^a5, a3^a6) are a bijection of each set, bit 4 is kept, so the two transforms of a
+// 32-lane group (offset 16) never meet.
+FHE_SWZ(7, 3, 1, 2, 4, 8, 18, 4, 9, 0, 0, 0, 0, 0, 0, 0, 0, 0)
 #undef FHE_SWZ
 
 template <class PL>
@@ -267,6 +273,41 @@ __device__ __forceinline__ void exchange_sync(int s_next) {
 template <class PL>
 struct FftConsts {
     cplx tw[PL::NTW > 0 ? PL::NTW : 1][PL::R];  // tw[s][q] = exp(-2 pi i q t' / S_s); tw[s][0] = 1 unused
+    __device__ __forceinline__ cplx get(int s, int q) const { return tw[s][q]; }
+};
+
+// The same constants kept in an LDS table shared by the workgroup instead of 4*NTW*R VGPRs per
+// thread (the large-N kernels need the registers for loads in flight).  Entry (s, q, t') sits at
+// off(s) + q * n_tp(s) + t': for a fixed q the threads of a transform read consecutive 16-byte
+// entries (conflict free), threads of different transforms broadcast.
+template <class PL>
+struct FftTwiddleTable {
+    __host__ __device__ static constexpr int n_tp(int s) { return 1 << (PL::log_S(s) - PL::LOGR); }
+    __host__ __device__ static constexpr int off(int s) {
+        int o = 0;
+        for (int i = 0; i < s; i++) o += PL::R * n_tp(i);
+        return o;
+    }
+    static constexpr int ENTRIES = off(PL::NTW);
+    const double2* base;
+    int tau;
+    __device__ __forceinline__ static void fill(double2* b, int tid, int nthreads) {
+#pragma unroll
+        for (int s = 0; s < PL::NTW; s++) {
+            const int ntp = n_tp(s);
+            for (int e = tid; e < PL::R * ntp; e += nthreads) {
+                const int q = e / ntp, tp = e % ntp;
+                double sn, cs;
+                sincospi(-2.0 * (double)(q * tp) / (double)(1 << PL::log_S(s)), &sn, &cs);
+                b[off(s) + e] = make_double2(cs, sn);
+            }
+        }
+    }
+    __device__ __forceinline__ cplx get(int s, int q) const {
+        const double2 v = base[off(s) + q * n_tp(s) + (tau & (n_tp(s) - 1))];
+        cplx r; r.re = v.x; r.im = v.y;
+        return r;
+    }
 };
 
 template <class PL>
@@ -458,8 +499,8 @@ __device__ __forceinline__ void swap10_inverse(cplx (*x)[4], const FftConsts<Fft
 
 // Forward transform.  In: x[m] = point (tau + T*m) of the (already twisted) input.
 // Out: x[rho] in last-pass layout.  `re`/`im` are this group's LDS planes (P doubles each).
-template <class PL>
-__device__ __forceinline__ void fft_forward(cplx* x, const FftConsts<PL>& c, double* re, double* im,
+template <class PL, class C>
+__device__ __forceinline__ void fft_forward(cplx* x, const C& c, double* re, double* im,
                                             int tau) {
     if constexpr (PL::SWAP) {
         swap10_forward<1>(reinterpret_cast<cplx(*)[4]>(x), c, re, 0, (int)(im - re), tau);
@@ -492,7 +533,7 @@ __device__ __forceinline__ void fft_forward(cplx* x, const FftConsts<PL>& c, dou
         }
         if (s < PL::NTW) {
 #pragma unroll
-            for (int q = 1; q < R; q++) x[q] = cmul(x[q], c.tw[s][q]);
+            for (int q = 1; q < R; q++) x[q] = cmul(x[q], c.get(s, q));
         }
         if (s + 1 < PL::NP) {
 #pragma unroll
@@ -510,8 +551,8 @@ __device__ __forceinline__ void fft_forward(cplx* x, const FftConsts<PL>& c, dou
 }
 
 // Inverse transform (unscaled).  In: x[rho] in last-pass layout.  Out: x[m] = point (tau + T*m).
-template <class PL>
-__device__ __forceinline__ void fft_inverse(cplx* x, const FftConsts<PL>& c, double* re, double* im,
+template <class PL, class C>
+__device__ __forceinline__ void fft_inverse(cplx* x, const C& c, double* re, double* im,
                                             int tau) {
     if constexpr (PL::SWAP) {
         swap10_inverse<1>(reinterpret_cast<cplx(*)[4]>(x), c, re, 0, (int)(im - re), tau);
@@ -538,7 +579,7 @@ __device__ __forceinline__ void fft_inverse(cplx* x, const FftConsts<PL>& c, dou
         }
         if (s < PL::NTW) {
 #pragma unroll
-            for (int q = 1; q < R; q++) x[q] = cmul_conj(x[q], c.tw[s][q]);
+            for (int q = 1; q < R; q++) x[q] = cmul_conj(x[q], c.get(s, q));
         }
         if (lr == PL::LOGR) {
             small_dft<R, true>(x);

@@ -35,14 +35,19 @@ struct BrLargeCfg {
     static constexpr int TA = PA::T, TB = PB::T;
     static constexpr int THREADS = 512;
     static constexpr int SUBS_A = THREADS / TA, SUBS_B = THREADS / TB;   // transforms in flight
-    static constexpr int SLOTS_A = 2 * P1 + 4, SLOTS_B = 2 * P2 + 4;     // LDS slots per transform
+    // LDS slots per transform: two planes + padding that puts neighbouring transforms 16 slots apart mod 32
+    static constexpr int SLOTS_A = 2 * P1 + 16, SLOTS_B = 2 * P2 + 16;
     static constexpr size_t LDS_PLANES =
         (size_t)(SUBS_A * SLOTS_A > SUBS_B * SLOTS_B ? SUBS_A * SLOTS_A : SUBS_B * SLOTS_B) * 8;
     // unit roots e^{2 pi i e / 2N}, e < 2N, as a product of two table entries (low / high bits of e):
     // replaces sincospi in the twist and inter-step twiddles (it was > half of the kernel's VALU work)
     static constexpr int ROOT_BITS = LOGN + 1, ROOT_LO = ROOT_BITS / 2, ROOT_HI = ROOT_BITS - ROOT_LO;
     static constexpr size_t LDS_ROOTS = ((size_t)(1 << ROOT_LO) + (size_t)(1 << ROOT_HI)) * 16;
-    static constexpr size_t LDS_BYTES = LDS_PLANES + LDS_ROOTS;
+    // inter-pass twiddles of the two sub-transforms as LDS tables (FftTwiddleTable) instead of
+    // 64 VGPRs each: the registers are needed for loads in flight
+    static constexpr size_t LDS_TW_A = (size_t)FftTwiddleTable<PA>::ENTRIES * 16;
+    static constexpr size_t LDS_TW_B = (size_t)FftTwiddleTable<PB>::ENTRIES * 16;
+    static constexpr size_t LDS_BYTES = LDS_PLANES + LDS_ROOTS + LDS_TW_A + LDS_TW_B;
     // per-LWE workspace in HBM (bytes): acc | tmp[L*K1][P] c64 | tmp2[K1][P] c64
     static constexpr size_t WS_ACC = (size_t)K1 * N * 8;
     static constexpr size_t WS_TMP = (size_t)L * K1 * P * 16;
@@ -125,7 +130,7 @@ struct RootTable {
 // column transform forward: x[m] holds point (a = tau + TA*m, column b); result slot rho is written to
 // dst[slot_addr * P2 + b] after the inter-step twiddle w_P^{-q1*b} (forward sign convention e^{-2 pi i})
 template <class CFG>
-__device__ __forceinline__ void column_forward_store(cplx* x, const FftConsts<typename CFG::PA>& fc, double* re,
+__device__ __forceinline__ void column_forward_store(cplx* x, const FftTwiddleTable<typename CFG::PA>& fc, double* re,
                                                      double* im, int tau, int b, double2* dst, const RootTable<CFG>& roots) {
     using PA = typename CFG::PA;
     fft_forward<PA>(x, fc, re, im, tau);
@@ -153,10 +158,12 @@ bsk_convert_large_kernel(const uint64_t* __restrict__ bsk_std, double* __restric
     const int tid = threadIdx.x;
     const int subA = tid / CFG::TA, tauA = tid % CFG::TA;
     const int subB = tid / CFG::TB, tauB = tid % CFG::TB;
-    FftConsts<PA> fca;
-    FftConsts<PB> fcb;
-    fft_init_consts<PA>(fca, tauA);
-    fft_init_consts<PB>(fcb, tauB);
+    double2* twa = reinterpret_cast<double2*>(smem + CFG::LDS_PLANES + CFG::LDS_ROOTS);
+    double2* twb = twa + FftTwiddleTable<PA>::ENTRIES;
+    FftTwiddleTable<PA>::fill(twa, threadIdx.x, CFG::THREADS);
+    FftTwiddleTable<PB>::fill(twb, threadIdx.x, CFG::THREADS);
+    const FftTwiddleTable<PA> fca{twa, tauA};
+    const FftTwiddleTable<PB> fcb{twb, tauB};
     double2* tmp = workspace + (size_t)blockIdx.x * P;
     RootTable<CFG> roots;
     roots.init(reinterpret_cast<double2*>(smem + CFG::LDS_PLANES), tid, CFG::THREADS);
@@ -230,10 +237,12 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
     double2* tmp2 = reinterpret_cast<double2*>(ws + CFG::WS_ACC + CFG::WS_TMP);        // [K1][P]
     const uint32_t bL = args.base_log * L;
 
-    FftConsts<PA> fca;
-    FftConsts<PB> fcb;
-    fft_init_consts<PA>(fca, tauA);
-    fft_init_consts<PB>(fcb, tauB);
+    double2* twa = reinterpret_cast<double2*>(smem + CFG::LDS_PLANES + CFG::LDS_ROOTS);
+    double2* twb = twa + FftTwiddleTable<PA>::ENTRIES;
+    FftTwiddleTable<PA>::fill(twa, threadIdx.x, CFG::THREADS);
+    FftTwiddleTable<PB>::fill(twb, threadIdx.x, CFG::THREADS);
+    const FftTwiddleTable<PA> fca{twa, tauA};
+    const FftTwiddleTable<PB> fcb{twb, tauB};
     RootTable<CFG> roots;
     roots.init(reinterpret_cast<double2*>(smem + CFG::LDS_PLANES), tid, NT);
 
@@ -267,29 +276,45 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
         const bool odd = (d >> LOGN) & 1;
 
         // ---- phase 1: decompose (acc*X^d - acc), twist, column transforms, twiddle -> tmp ----
-        for (int p = 0; p < K1; p++) {
-            const uint64_t* ap = acc + (size_t)p * N;
-            for (int b0 = 0; b0 < P2; b0 += CFG::SUBS_A) {
-                const int b = b0 + subA;
+        // The accumulator words of iteration t+1 are requested before iteration t is transformed
+        // (the exchanges' wavefront fences would otherwise pin the loads behind the FFT).
+        {
+            constexpr int COLS = P2 / CFG::SUBS_A, ITERS = K1 * COLS;
+            using state_t = typename std::conditional<(L >= 3), uint64_t, uint32_t>::type;
+            uint64_t rot[2 * R], own[2 * R];
+            auto issue = [&](int t) {
+                const int b = (t % COLS) * CFG::SUBS_A + subA;
+                const uint64_t* ap = acc + (size_t)(t / COLS) * N;
+#pragma unroll
+                for (int m = 0; m < R; m++) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const uint32_t j = (tauA + CFG::TA * m) * P2 + b + h * P;
+                        rot[2 * m + h] = ap[CFG::aix((j - rem) & (N - 1))];
+                        own[2 * m + h] = ap[CFG::aix(j)];
+                    }
+                }
+            };
+            issue(0);
+            for (int t = 0; t < ITERS; t++) {
+                const int p = t / COLS, b = (t % COLS) * CFG::SUBS_A + subA;
                 // decomposition state: 32 bits suffice while base_log * level <= 31 (L <= 2 here)
-                using state_t = typename std::conditional<(L >= 3), uint64_t, uint32_t>::type;
                 state_t st_lo[R], st_hi[R];
 #pragma unroll
                 for (int m = 0; m < R; m++) {
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         const uint32_t j = (tauA + CFG::TA * m) * P2 + b + h * P;
-                        const uint32_t src = (j - rem) & (N - 1);
                         const bool neg = (j < rem) != odd;
-                        uint64_t v = ap[CFG::aix(src)];
+                        uint64_t v = rot[2 * m + h];
                         v = neg ? (0 - v) : v;
-                        const uint64_t own = ap[CFG::aix(j)];
                         state_t st;
-                        if constexpr (L >= 3) st = decomp_init_state64(v - own, bL);
-                        else st = decomp_init_state(v - own, bL);
+                        if constexpr (L >= 3) st = decomp_init_state64(v - own[2 * m + h], bL);
+                        else st = decomp_init_state(v - own[2 * m + h], bL);
                         if (h == 0) st_lo[m] = st; else st_hi[m] = st;
                     }
                 }
+                if (t + 1 < ITERS) issue(t + 1);
 #pragma unroll
                 for (int it = 0; it < L; it++) {
                     cplx x[R];
@@ -317,32 +342,43 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
         for (int r0 = 0; r0 < P1; r0 += CFG::SUBS_B) {
             const int r = r0 + subB;
             cplx outf[K1][R];
+            // (it, row) pairs in the order the reference accumulates them (ggsw.rs:524); the spectrum
+            // row of pair u+1 and the GGSW rows of pair u are in flight while pair u is transformed
+            constexpr int PAIRS = L * K1;
+            double2 xin[R];
+            auto issue_row = [&](int u) {
+                const double2* spoly = tmp + (size_t)u * P;          // u = it * K1 + row
 #pragma unroll
-            for (int it = 0; it < L; it++) {
+                for (int m = 0; m < R; m++) xin[m] = spoly[CFG::tix(r, tauB + CFG::TB * m)];
+            };
+            issue_row(0);
+#pragma unroll
+            for (int u = 0; u < PAIRS; u++) {
+                const int it = u / K1, row = u % K1;
                 const int lvl_idx = L - 1 - it;                      // ggsw.rs:524
+                cplx x[R];
 #pragma unroll
-                for (int row = 0; row < K1; row++) {
-                    cplx x[R];
-                    const double2* spoly = tmp + (size_t)(it * K1 + row) * P;
+                for (int m = 0; m < R; m++) { x[m].re = xin[m].x; x[m].im = xin[m].y; }
+                double2 bv[K1][R];
 #pragma unroll
-                    for (int m = 0; m < R; m++) {
-                        const double2 v = spoly[CFG::tix(r, tauB + CFG::TB * m)];
-                        x[m].re = v.x; x[m].im = v.y;
-                    }
-                    fft_forward<PB>(x, fcb, breB, bimB, tauB);
+                for (int col = 0; col < K1; col++) {
+                    const double2* bk = bk0 + (((size_t)lvl_idx * K1 + row) * K1 + col) * P + (size_t)r * P2;
 #pragma unroll
-                    for (int col = 0; col < K1; col++) {
-                        const double2* bk = bk0 + (((size_t)lvl_idx * K1 + row) * K1 + col) * P + (size_t)r * P2;
+                    for (int rho = 0; rho < R; rho++) bv[col][rho] = bk[rho * CFG::TB + tauB];
+                }
+                if (u + 1 < PAIRS) issue_row(u + 1);
+                fft_forward<PB>(x, fcb, breB, bimB, tauB);
 #pragma unroll
-                        for (int rho = 0; rho < R; rho++) {
-                            const double2 bv = bk[rho * CFG::TB + tauB];
-                            if (it == 0 && row == 0) {
-                                outf[col][rho].re = bv.x * x[rho].re - bv.y * x[rho].im;
-                                outf[col][rho].im = bv.x * x[rho].im + bv.y * x[rho].re;
-                            } else {
-                                outf[col][rho].re = fma(bv.x, x[rho].re, fma(-bv.y, x[rho].im, outf[col][rho].re));
-                                outf[col][rho].im = fma(bv.x, x[rho].im, fma(bv.y, x[rho].re, outf[col][rho].im));
-                            }
+                for (int col = 0; col < K1; col++) {
+#pragma unroll
+                    for (int rho = 0; rho < R; rho++) {
+                        const double2 b2 = bv[col][rho];
+                        if (u == 0) {
+                            outf[col][rho].re = b2.x * x[rho].re - b2.y * x[rho].im;
+                            outf[col][rho].im = b2.x * x[rho].im + b2.y * x[rho].re;
+                        } else {
+                            outf[col][rho].re = fma(b2.x, x[rho].re, fma(-b2.y, x[rho].im, outf[col][rho].re));
+                            outf[col][rho].im = fma(b2.x, x[rho].im, fma(b2.y, x[rho].re, outf[col][rho].im));
                         }
                     }
                 }
@@ -375,14 +411,21 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
                     const double2 v = sp[CFG::tix(slot_addr<PA>(tauA, rho), b)];
                     x[rho].re = v.x; x[rho].im = v.y;
                 }
+                uint64_t a_lo[R], a_hi[R];      // requested now, needed after the transform
+#pragma unroll
+                for (int m = 0; m < R; m++) {
+                    const size_t ja = CFG::aix((uint32_t)((tauA + CFG::TA * m) * P2 + b));
+                    a_lo[m] = ap[ja];
+                    a_hi[m] = ap[ja + P];
+                }
                 fft_inverse<PA>(x, fca, areA, aimA, tauA);
 #pragma unroll
                 for (int m = 0; m < R; m++) {
                     const int j = (tauA + CFG::TA * m) * P2 + b;
                     const cplx t = cmul_conj(x[m], roots.get((uint32_t)j));
                     const size_t ja = CFG::aix((uint32_t)j);
-                    ap[ja] += from_torus(t.re);
-                    ap[ja + P] += from_torus(t.im);
+                    ap[ja] = a_lo[m] + from_torus(t.re);
+                    ap[ja + P] = a_hi[m] + from_torus(t.im);
                 }
             }
         }
