@@ -5,8 +5,9 @@ sys.path.insert(0, "fhe-string-bounty_amd")
 import fhestr
 P = fhestr.Params(996, 1, 32768, 15, 2, 3, 7, 16, 16, 6.767666038309478e-08, 2.168404344971009e-19, "PARAM_MESSAGE_4_CARRY_4_KS_PBS")
 ck = fhestr.ClientKey(P, 0x5EED0005)
-t = time.time(); bsk, ksk = ck.gen_server_keys(16); print(f"keygen {time.time() - t:.1f} s", flush=True)
-eng = fhestr.Engine(P, 0); eng.load_keys(bsk, ksk); del bsk, ksk
+eng = fhestr.Engine(P, 0)
+g, sm = ck.secret_keys()
+t = time.time(); eng.generate_keys(g, sm, 0x5EED0005); print(f"device keygen {time.time() - t:.1f} s", flush=True)
 ops = fhestr.FheStringOps(eng)
 rng = np.random.default_rng(0x5EED0005)
 words = [b"The ", b"quick ", b"BROWN ", b"fox ", b"Jumps ", b"over ", b"the ", b"LAZY ", b"dog. "]
