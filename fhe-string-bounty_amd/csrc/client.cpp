@@ -86,13 +86,23 @@ struct ClientKey {
         }
     }
     // lwe_bootstrap_key_generation.rs:76-135 + ggsw_encryption.rs:72-151,300-331
-    void gen_bsk_range(uint64_t* bsk, size_t lo, size_t hi) const {
+    // plaintext bit of every GGSW of the key (classic: the small key; multi-bit: per-group products)
+    std::vector<uint64_t> ggsw_bits() const {
+        const uint32_t ng = n_ggsw(p), gf = p.grouping_factor > 1 ? p.grouping_factor : 1;
+        std::vector<uint64_t> bits(ng);
+        for (uint32_t i = 0; i < ng; i++)
+            bits[i] = gf == 1 ? small_sk[i]
+                              : multi_bit_key_bit(small_sk.data() + (size_t)(i >> gf) * gf, gf, i & ((1u << gf) - 1));
+        return bits;
+    }
+    // (multi-bit: lwe_multi_bit_bootstrap_key_generation.rs:87-173, the same GGSW encryption per entry)
+    void gen_bsk_range(uint64_t* bsk, const uint64_t* bits, size_t lo, size_t hi) const {
         const uint32_t N = p.N, k = p.k, k1 = k + 1, L = p.pbs_level;
         const size_t glwe_len = (size_t)k1 * N, ggsw_len = (size_t)L * k1 * glwe_len;
         for (size_t i = lo; i < hi; i++) {
             Rng r(seed, 0x42534B0000000000ull + i);
             uint64_t* ggsw = bsk + i * ggsw_len;
-            const uint64_t m = small_sk[i];
+            const uint64_t m = bits[i];
             for (uint32_t li = 0; li < L; li++) {
                 const uint64_t factor = (0 - m) * (1ull << (64 - p.pbs_base_log * (li + 1)));
                 for (uint32_t row = 0; row < k1; row++) {
@@ -112,9 +122,12 @@ struct ClientKey {
     }
     void gen_bsk(uint64_t* bsk, int threads) const {
         if (threads < 1) threads = 1;
+        const std::vector<uint64_t> bits = ggsw_bits();
+        const size_t ng = bits.size();
+        const uint64_t* b = bits.data();
         std::vector<std::thread> pool;
         for (int t = 0; t < threads; t++)
-            pool.emplace_back([=] { gen_bsk_range(bsk, (size_t)p.n * t / threads, (size_t)p.n * (t + 1) / threads); });
+            pool.emplace_back([=] { gen_bsk_range(bsk, b, ng * t / threads, ng * (t + 1) / threads); });
         for (auto& th : pool) th.join();
     }
 };
@@ -129,7 +142,7 @@ extern "C" {
 
 size_t fhe_params_ksk_len(const fhe_params_t* p) { return (size_t)p->k * p->N * p->ks_level * (p->n + 1); }
 size_t fhe_params_bsk_len(const fhe_params_t* p) {
-    return (size_t)p->n * p->pbs_level * (p->k + 1) * (p->k + 1) * p->N;
+    return (size_t)fhe::n_ggsw(*p) * p->pbs_level * (p->k + 1) * (p->k + 1) * p->N;
 }
 
 int fhe_client_key_create(const fhe_params_t* params, uint64_t seed, fhe_client_key** out) {

@@ -11,6 +11,18 @@
 
 namespace fhe {
 
+// GGSWs in the bootstrapping key: n (classic PBS) or n/g * 2^g (multi-bit, grouping factor g)
+inline uint32_t n_ggsw(const fhe_params_t& p) {
+    return p.grouping_factor > 1 ? p.n / p.grouping_factor * (1u << p.grouping_factor) : p.n;
+}
+// plaintext bit GGSW `sel` of a group encrypts (lwe_multi_bit_bootstrap_key_generation.rs:401-427):
+// product over the group's key bits of (s_b if selector bit g-1-b is set else 1 - s_b)
+inline uint64_t multi_bit_key_bit(const uint64_t* group_bits, uint32_t g, uint32_t sel) {
+    uint64_t prod = 1;
+    for (uint32_t b = 0; b < g; b++) prod *= group_bits[b] ^ (((sel >> (g - 1 - b)) & 1) ^ 1);
+    return prod;
+}
+
 extern thread_local std::string g_last_error;
 int fail(const std::string& msg);
 

@@ -17,6 +17,7 @@
 #include "lwe_kernels.hip.h"
 #include "pbs_kernels.hip.h"
 #include "pbs_large_kernels.hip.h"
+#include "pbs_multibit_kernels.hip.h"
 
 namespace fhe {
 
@@ -39,6 +40,8 @@ struct BrVariant {
     int logN, k1, L, logR;
     bool wide;          // true: every thread carries all k+1 polynomials (blind_rotate_wide_kernel)
     bool large;         // true: four-step FFT through an HBM workspace (blind_rotate_large_kernel)
+    int grouping = 1;   // > 1: multi-bit PBS kernel for that grouping factor
+    int lds_per_n = 4;  // dynamic LDS bytes per small-LWE coefficient (modulus-switched mask / degrees)
     size_t ws_bytes;    // per-LWE workspace (large only)
     size_t convert_ws;  // per-workgroup workspace of the conversion kernel (large only)
     int threads;
@@ -91,11 +94,24 @@ BrVariant make_large_variant() {
     return v;
 }
 
+template <int LOGN, int LOGR, int K1, int G>
+BrVariant make_multibit_variant() {
+    using CFG = BrMultiBitCfg<LOGN, LOGR, K1, G>;
+    BrVariant v = make_variant<LOGN, LOGR, K1, 1>();   // same Fourier key slot order + conversion kernel
+    v.grouping = G;
+    v.lds_bytes = CFG::LDS_FIXED;
+    v.lds_per_n = 4 * ((1 << G) - 1) / G + 4;         // (n/G) * (2^G - 1) degrees, rounded up
+    v.rotate_fn = reinterpret_cast<const void*>(&blind_rotate_multibit_kernel<LOGN, LOGR, K1, G>);
+    return v;
+}
+
 static const std::vector<BrVariant>& variants() {
     static const std::vector<BrVariant> v = {
         // PARAM_MESSAGE_2_CARRY_2_KS_PBS: N=2048, k=1, l=1  (first entry of a shape = default)
         make_variant<11, 2, 2, 1>(), make_variant<11, 3, 2, 1>(), make_variant<11, 4, 2, 1>(),
         make_wide_variant<11, 2, 2, 1>(), make_wide_variant<11, 3, 2, 1>(),
+        // PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS: multi-bit PBS, grouping factor 2
+        make_multibit_variant<11, 2, 2, 2>(),
         // N=1024, k=2, l=1 family (PARAM_MESSAGE_2_CARRY_1_KS_PBS ...)
         make_variant<10, 3, 3, 1>(), make_variant<10, 2, 3, 1>(), make_wide_variant<10, 2, 3, 1>(),
         // PARAM_MESSAGE_1_CARRY_1_KS_PBS: N=512, k=3, l=1
@@ -122,8 +138,9 @@ static const BrVariant* find_variant(const fhe_params_t& p, int selector) {
     while ((1u << logN) < p.N) logN++;
     const int logR = selector & 15;
     const bool wide = (selector & 16) != 0;
+    const int grouping = p.grouping_factor > 1 ? (int)p.grouping_factor : 1;
     for (const auto& v : variants())
-        if (v.logN == logN && v.k1 == (int)p.k + 1 && v.L == (int)p.pbs_level &&
+        if (v.logN == logN && v.k1 == (int)p.k + 1 && v.L == (int)p.pbs_level && v.grouping == grouping &&
             (selector == 0 || (v.logR == logR && v.wide == wide)))
             return &v;
     return nullptr;
@@ -141,7 +158,8 @@ int Engine::create(const fhe_params_t& p, int device, Engine** out) {
     int env_logr = 0;
     if (const char* e = getenv("FHESTR_LOG2_POINTS")) env_logr = atoi(e);
     const BrVariant* v = find_variant(p, env_logr);
-    if (!v) return fail("no blind-rotation kernel instantiated for this (N, k, level)");
+    if (p.grouping_factor > 1 && (p.n % p.grouping_factor) != 0) return fail("grouping factor must divide n");
+    if (!v) return fail("no blind-rotation kernel instantiated for this (N, k, level, grouping factor)");
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     if (count <= 0) return fail("no HIP device: libfhestr has no CPU fallback");
@@ -216,9 +234,9 @@ int Engine::set_variant(int logR) {
     }
     if (d_fbsk) {
         HIP_TRY(hipFuncSetAttribute(variant->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(variant->lds_bytes + (size_t)p.n * 4)));
+                                    (int)(variant->lds_bytes + (size_t)p.n * variant->lds_per_n)));
         HIP_TRY(hipFuncSetAttribute(variant_large->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(variant_large->lds_bytes + (size_t)p.n * 4)));
+                                    (int)(variant_large->lds_bytes + (size_t)p.n * variant_large->lds_per_n)));
     }
     return 0;
 }
@@ -226,7 +244,7 @@ int Engine::set_variant(int logR) {
 int Engine::load_keys(const uint64_t* bsk_std, const uint64_t* ksk) {
     if (use()) return 1;
     const size_t ksk_len = (size_t)p.k * p.N * p.ks_level * (p.n + 1);
-    const size_t bsk_len = (size_t)p.n * p.pbs_level * (p.k + 1) * (p.k + 1) * p.N;
+    const size_t bsk_len = (size_t)n_ggsw(p) * p.pbs_level * (p.k + 1) * (p.k + 1) * p.N;
     uint64_t *d_ksk_std = nullptr, *d_bsk_std = nullptr;
     HIP_TRY(hipMalloc((void**)&d_ksk_std, ksk_len * 8));
     if (hipMalloc((void**)&d_bsk_std, bsk_len * 8) != hipSuccess) {
@@ -249,32 +267,40 @@ int Engine::generate_keys(const uint64_t* glwe_sk, const uint64_t* small_sk, uin
     if (use()) return 1;
     const size_t in_dim = (size_t)p.k * p.N;
     const size_t ksk_len = in_dim * p.ks_level * (p.n + 1);
-    const size_t bsk_len = (size_t)p.n * p.pbs_level * (p.k + 1) * (p.k + 1) * p.N;
+    const size_t bsk_len = (size_t)n_ggsw(p) * p.pbs_level * (p.k + 1) * (p.k + 1) * p.N;
     for (size_t i = 0; i < in_dim; i++)
         if (glwe_sk[i] > 1) return fail("glwe_sk must be binary");
     for (size_t i = 0; i < p.n; i++)
         if (small_sk[i] > 1) return fail("small_sk must be binary");
-    uint64_t *d_gsk = nullptr, *d_ssk = nullptr, *d_ksk_std = nullptr, *d_bsk_std = nullptr;
+    // plaintext bit of every GGSW: the key bits themselves, or their per-group products (multi-bit)
+    const uint32_t ng = n_ggsw(p), gf = p.grouping_factor > 1 ? p.grouping_factor : 1;
+    std::vector<uint64_t> bits(ng);
+    for (uint32_t i = 0; i < ng; i++)
+        bits[i] = gf == 1 ? small_sk[i] : multi_bit_key_bit(small_sk + (size_t)(i >> gf) * gf, gf, i & ((1u << gf) - 1));
+    uint64_t *d_gsk = nullptr, *d_ssk = nullptr, *d_bits = nullptr, *d_ksk_std = nullptr, *d_bsk_std = nullptr;
     auto cleanup = [&] {
-        (void)hipFree(d_gsk); (void)hipFree(d_ssk); (void)hipFree(d_ksk_std); (void)hipFree(d_bsk_std);
+        (void)hipFree(d_gsk); (void)hipFree(d_ssk); (void)hipFree(d_bits); (void)hipFree(d_ksk_std); (void)hipFree(d_bsk_std);
     };
     hipError_t e = hipMalloc((void**)&d_gsk, in_dim * 8);
     if (e == hipSuccess) e = hipMalloc((void**)&d_ssk, (size_t)p.n * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_bits, (size_t)ng * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_bits, bits.data(), (size_t)ng * 8, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMalloc((void**)&d_ksk_std, ksk_len * 8);
     if (e == hipSuccess) e = hipMalloc((void**)&d_bsk_std, bsk_len * 8);
     if (e == hipSuccess) e = hipMemcpyAsync(d_gsk, glwe_sk, in_dim * 8, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_ssk, small_sk, (size_t)p.n * 8, hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) { cleanup(); return fail(std::string("generate_keys: ") + hipGetErrorString(e)); }
-    KeygenArgs a{d_gsk, d_ssk, d_ksk_std, d_bsk_std, seed, p.n, p.k, p.N,
+    KeygenArgs a{d_gsk, d_ssk, d_bits, d_ksk_std, d_bsk_std, seed, p.n, p.k, p.N,
                  p.pbs_base_log, p.pbs_level, p.ks_base_log, p.ks_level, p.lwe_std, p.glwe_std};
     hipLaunchKernelGGL(ksk_gen_kernel, dim3((unsigned)((in_dim + 63) / 64)), dim3(64), 0, stream, a);
-    hipLaunchKernelGGL(bsk_gen_kernel, dim3(p.n), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(bsk_gen_kernel, dim3(ng), dim3(256), 0, stream, a);
     e = hipGetLastError();
     if (e == hipSuccess && ksk_out) e = hipMemcpyAsync(ksk_out, d_ksk_std, ksk_len * 8, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess && bsk_std_out) e = hipMemcpyAsync(bsk_std_out, d_bsk_std, bsk_len * 8, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     (void)hipFree(d_gsk); d_gsk = nullptr;
     (void)hipFree(d_ssk); d_ssk = nullptr;
+    (void)hipFree(d_bits); d_bits = nullptr;
     if (e != hipSuccess) { cleanup(); return fail(std::string("generate_keys: ") + hipGetErrorString(e)); }
     return install_keys(d_ksk_std, d_bsk_std);
 }
@@ -286,7 +312,7 @@ int Engine::install_keys(uint64_t* d_ksk_std, uint64_t* d_std) {
         uint64_t*& a; uint64_t*& b;
         ~Guard() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); }
     } guard{d_ksk_std, d_std};
-    const size_t bsk_len = (size_t)p.n * p.pbs_level * (p.k + 1) * (p.k + 1) * p.N;
+    const size_t bsk_len = (size_t)n_ggsw(p) * p.pbs_level * (p.k + 1) * (p.k + 1) * p.N;
     if (d_ksk) { HIP_TRY(hipFree(d_ksk)); d_ksk = nullptr; }
     if (d_fbsk) { HIP_TRY(hipFree(d_fbsk)); d_fbsk = nullptr; }
     if (d_ksk_packed) { HIP_TRY(hipFree(d_ksk_packed)); d_ksk_packed = nullptr; }
@@ -324,9 +350,9 @@ int Engine::install_keys(uint64_t* d_ksk_std, uint64_t* d_std) {
         HIP_TRY(hipStreamSynchronize(stream));
     }
     HIP_TRY(hipFuncSetAttribute(variant->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(variant->lds_bytes + (size_t)p.n * 4)));
+                                (int)(variant->lds_bytes + (size_t)p.n * variant->lds_per_n)));
     HIP_TRY(hipFuncSetAttribute(variant_large->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(variant_large->lds_bytes + (size_t)p.n * 4)));
+                                (int)(variant_large->lds_bytes + (size_t)p.n * variant_large->lds_per_n)));
     return 0;
 }
 
@@ -427,7 +453,7 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
         return 0;
     }
     HIP_TRY(hipLaunchKernel(v->rotate_fn, dim3(count), dim3(v->threads), args,
-                            v->lds_bytes + (size_t)p.n * 4, stream));
+                            v->lds_bytes + (size_t)p.n * v->lds_per_n, stream));
     return 0;
 }
 

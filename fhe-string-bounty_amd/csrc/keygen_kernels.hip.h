@@ -22,6 +22,8 @@ namespace fhe {
 struct KeygenArgs {
     const uint64_t* glwe_sk;    // [k*N] 0/1 (also the big LWE key)
     const uint64_t* small_sk;   // [n]   0/1
+    const uint64_t* bsk_bits;   // [n_ggsw] plaintext bit of every GGSW (classic: = small_sk; multi-bit:
+                                // products of the group's key bits, engine.h multi_bit_key_bit)
     uint64_t* ksk;              // [k*N][ks_level][n+1]
     uint64_t* bsk;              // [n][pbs_level][k+1][k+1][N]
     uint64_t seed;
@@ -56,7 +58,7 @@ __global__ void __launch_bounds__(64) ksk_gen_kernel(KeygenArgs a) {
     }
 }
 
-// One workgroup per small-key coefficient i (GGSW number i).  For every GLWE row of the GGSW:
+// One workgroup per GGSW i of the key (classic: small-key coefficient i).  For every GLWE row of the GGSW:
 // thread 0 draws the mask and the noise in stream order (the only sequential part), then all threads
 // add the plaintext term and  sum_q A_q * S_q  (binary key: signed shifted adds, negacyclic).
 __global__ void __launch_bounds__(256) bsk_gen_kernel(KeygenArgs a) {
@@ -64,7 +66,7 @@ __global__ void __launch_bounds__(256) bsk_gen_kernel(KeygenArgs a) {
     const uint32_t N = a.N, k = a.k, k1 = k + 1, L = a.pbs_level;
     const size_t glwe_len = (size_t)k1 * N, ggsw_len = (size_t)L * k1 * glwe_len;
     uint64_t* ggsw = a.bsk + (size_t)i * ggsw_len;
-    const uint64_t m = a.small_sk[i];
+    const uint64_t m = a.bsk_bits[i];
     Rng r(a.seed, BSK_STREAM + i);          // only thread 0's copy advances
     for (uint32_t li = 0; li < L; li++) {
         const uint64_t factor = (0 - m) * (1ull << (64 - a.pbs_base_log * (li + 1)));

@@ -1,0 +1,235 @@
+// pbs_multibit_kernels.hip.h -- multi-bit programmable bootstrap (grouping factor G) for gfx950.
+//
+// Replaces multi_bit_blind_rotate_assign / multi_bit_programmable_bootstrap_lwe_ciphertext
+//   tfhe/src/core_crypto/algorithms/lwe_multi_bit_programmable_bootstrapping.rs:18-83 (prepare_multi_bit_ggsw),
+//   :295-546 (blind rotation: one external product per group of G mask elements), :1035-1127 (PBS)
+// for the parameter shape of PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS (N = 2048, k = 1, one level).
+//
+// The reference pipelines "build the group's GGSW" (CPU threads) against "external product"
+// (one thread).  Here one workgroup per LWE does both inside the step, thread-locally:
+//   * the Fourier key holds 2^G GGSWs per group; GGSW `sel` is multiplied by the transform of the
+//     monomial X^{ms(sum of the selected mask elements)}.  In this engine's spectrum order slot
+//     (rho, tau) carries the value at zeta = w^(1 - 4 f), w = e^{i pi / N}, f = f_tau + 256 rho, so the
+//     monomial's transform at that slot is w^{d (1 - 4 f)} = w^{d (1 - 4 f_tau)} * (-i)^{d rho}: one
+//     root-table lookup per selector per thread, the four register slots follow by quarter turns;
+//   * the step is a plain external product acc <- GGSW (x) acc (no rotate-and-subtract), so the
+//     accumulator is decomposed straight out of its registers: no LDS copy of the accumulator, no
+//     gather, and only the two barriers of the forward / inverse transforms remain per step --
+//     n/G steps instead of n.
+// Thread layout, FFT plan and Fourier-key slot order are those of blind_rotate_kernel with the
+// FftSwap10 plan (pbs_kernels.hip.h); the key is converted by the same bsk_convert_kernel.
+#pragma once
+#include "pbs_kernels.hip.h"
+
+namespace fhe {
+
+template <int LOGN, int LOGR, int K1, int G>
+struct BrMultiBitCfg {
+    using Base = BrCfg<LOGN, LOGR, K1, 1>;
+    using PL = typename Base::PL;
+    static constexpr int N = Base::N, P = Base::P, R = Base::R, T = Base::T;
+    static constexpr int THREADS = Base::THREADS;
+    static constexpr int SEL = (1 << G) - 1;                   // monomial-carrying GGSWs per group
+    static constexpr int ROOT_LO_BITS = (LOGN + 1) / 2, ROOT_HI_BITS = LOGN + 1 - ROOT_LO_BITS;
+    // LDS: forward planes + inverse planes (as the classic split kernel) + two-level root table of
+    // e^{i pi m / N}, m < 2N; the per-group monomial degrees ((n/G) * SEL u32) follow dynamically
+    static constexpr size_t LDS_ROOTS = ((size_t)(1 << ROOT_LO_BITS) + (size_t)(1 << ROOT_HI_BITS)) * 16;
+    static constexpr size_t LDS_FIXED = 2 * (size_t)K1 * Base::GROUP_SLOTS * 8 + LDS_ROOTS;
+};
+
+template <int LOGN, int LOGR, int K1, int G>
+__global__ void __launch_bounds__((BrMultiBitCfg<LOGN, LOGR, K1, G>::THREADS))
+blind_rotate_multibit_kernel(BlindRotateArgs args) {
+    using CFG = BrMultiBitCfg<LOGN, LOGR, K1, G>;
+    using BASE = typename CFG::Base;
+    using PL = typename CFG::PL;
+    static_assert(PL::SWAP, "multi-bit kernel is written for the FftSwap10 plan");
+    constexpr int N = CFG::N, P = CFG::P, R = CFG::R, T = CFG::T, SEL = CFG::SEL;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* lds_x = reinterpret_cast<double*>(smem);                              // [K1][GROUP_SLOTS]
+    double* lds_f = lds_x + (size_t)K1 * BASE::GROUP_SLOTS;                       // [K1][GROUP_SLOTS]
+    double2* root_lo = reinterpret_cast<double2*>(lds_f + (size_t)K1 * BASE::GROUP_SLOTS);
+    double2* root_hi = root_lo + (1 << CFG::ROOT_LO_BITS);
+    uint32_t* lds_deg = reinterpret_cast<uint32_t*>(root_hi + (1 << CFG::ROOT_HI_BITS));   // [n/G][SEL]
+
+    const int g = threadIdx.x / T, tau = threadIdx.x % T;
+    const uint32_t sample = blockIdx.x;
+    const uint32_t n = args.n, groups = n / G;
+    const uint64_t* lwe = args.lwe_small + (size_t)sample * (n + 1);
+    const uint64_t* lut = args.luts + (size_t)(args.lut_idx ? args.lut_idx[sample] : 0) * K1 * N;
+    double* xre = lds_x + (size_t)g * BASE::GROUP_SLOTS;
+    double* xim = xre + BASE::PLANE;
+    const uint32_t bL = args.base_log;
+
+    // monomial degrees of every group (:57-70: wrapping sum of the selected mask elements, then
+    // modulus switch), selector bit G-1-b <-> mask element b
+    for (uint32_t e = threadIdx.x; e < groups * SEL; e += CFG::THREADS) {
+        const uint32_t grp = e / SEL, sel = e % SEL + 1;
+        uint64_t sum = 0;
+#pragma unroll
+        for (int b = 0; b < G; b++)
+            if ((sel >> (G - 1 - b)) & 1) sum += lwe[(size_t)grp * G + b];
+        lds_deg[e] = modulus_switch(sum, LOGN);
+    }
+    // e^{i pi m / N} = root_lo[m & mask] * root_hi[m >> ROOT_LO_BITS]
+    for (int e = threadIdx.x; e < (1 << CFG::ROOT_LO_BITS); e += CFG::THREADS) {
+        double sn, cs;
+        sincospi((double)e / (double)N, &sn, &cs);
+        root_lo[e] = make_double2(cs, sn);
+    }
+    for (int e = threadIdx.x; e < (1 << CFG::ROOT_HI_BITS); e += CFG::THREADS) {
+        double sn, cs;
+        sincospi((double)((size_t)e << CFG::ROOT_LO_BITS) / (double)N, &sn, &cs);
+        root_hi[e] = make_double2(cs, sn);
+    }
+
+    FftConsts<PL> fc;
+    fft_init_consts<PL>(fc, tau);
+    cplx twist[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        double sn, cs;
+        sincospi((double)PL::point(tau, m) / (double)N, &sn, &cs);
+        twist[m].re = cs; twist[m].im = sn;
+    }
+    // frequency of register slot 0 of this thread (FftSwap10: regs k4 | wave k3 | lane(5,4) k2 |
+    // lane(3,2) k0 | lane(1,0) k1, f = k0 + 4 k1 + 16 k2 + 64 k3 + 256 k4) and 1 - 4 f mod 2N
+    const int lane = tau & 63, wv = tau >> 6;
+    const uint32_t f_tau = ((lane >> 2) & 3) + 4 * (lane & 3) + 16 * (lane >> 4) + 64 * wv;
+    const uint32_t c_tau = (1u - 4u * f_tau) & (2u * N - 1u);
+
+    // acc <- LUT * X^{-ms(body)}
+    uint64_t acc_lo[R], acc_hi[R];
+    {
+        const uint32_t d = modulus_switch(lwe[n], LOGN);
+        const uint32_t rem = d & (N - 1);
+        const bool odd = (d >> LOGN) & 1;
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t j = PL::point(tau, m) + h * P;
+                const uint32_t src = (j + rem) & (N - 1);
+                const bool neg = ((j + rem) >= (uint32_t)N) != odd;
+                uint64_t v = lut[(size_t)g * N + src];
+                v = neg ? (0 - v) : v;
+                if (h == 0) acc_lo[m] = v; else acc_hi[m] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    const double2* fbsk = reinterpret_cast<const double2*>(args.fbsk);
+    constexpr size_t GGSW_ELEMS = (size_t)K1 * K1 * P;
+
+    for (uint32_t grp = 0; grp < groups; grp++) {
+        // ---- this group's GGSW, column g, rows (g + r) % K1: G0 + sum_sel G_sel * monomial_sel ----
+        const double2* gk = fbsk + (size_t)grp * (SEL + 1) * GGSW_ELEMS;
+        cplx comb[K1][R];
+#pragma unroll
+        for (int r = 0; r < K1; r++) {
+            const int row = (g + r) % K1;
+#pragma unroll
+            for (int rho = 0; rho < R; rho++) {
+                const double2 v = gk[((size_t)row * K1 + g) * P + rho * T + tau];
+                comb[r][rho].re = v.x; comb[r][rho].im = v.y;
+            }
+        }
+#pragma unroll
+        for (int s = 1; s <= SEL; s++) {
+            const uint32_t d = lds_deg[grp * SEL + (s - 1)];
+            const double2* gs = gk + (size_t)s * GGSW_ELEMS;
+            double2 gv[K1][R];
+#pragma unroll
+            for (int r = 0; r < K1; r++) {
+                const int row = (g + r) % K1;
+#pragma unroll
+                for (int rho = 0; rho < R; rho++) gv[r][rho] = gs[((size_t)row * K1 + g) * P + rho * T + tau];
+            }
+            // monomial transform at slot rho: w^{d (1 - 4 f_tau)} * (-i)^{d rho}
+            const uint32_t mi = (d * c_tau) & (2u * N - 1u);
+            const double2 a = root_lo[mi & ((1u << CFG::ROOT_LO_BITS) - 1u)], b = root_hi[mi >> CFG::ROOT_LO_BITS];
+            cplx mono;
+            mono.re = a.x * b.x - a.y * b.y;
+            mono.im = a.x * b.y + a.y * b.x;
+            // (-i)^d as a complex number with entries in {0, +-1}
+            const int q = d & 3;
+            cplx turn;
+            turn.re = q == 0 ? 1.0 : q == 2 ? -1.0 : 0.0;
+            turn.im = q == 1 ? -1.0 : q == 3 ? 1.0 : 0.0;
+#pragma unroll
+            for (int rho = 0; rho < R; rho++) {
+#pragma unroll
+                for (int r = 0; r < K1; r++) {
+                    const double2 v = gv[r][rho];
+                    comb[r][rho].re = fma(v.x, mono.re, fma(-v.y, mono.im, comb[r][rho].re));
+                    comb[r][rho].im = fma(v.x, mono.im, fma(v.y, mono.re, comb[r][rho].im));
+                }
+                mono = cmul(mono, turn);
+            }
+        }
+
+        // ---- external product acc <- GGSW (x) acc (ggsw.rs:477-598 on a zeroed destination) ----
+        cplx x[K1][R];
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            cplx z;
+            z.re = (double)decomp_single_digit(acc_lo[m], bL);
+            z.im = (double)decomp_single_digit(acc_hi[m], bL);
+            x[0][m] = cmul(z, twist[m]);
+        }
+        swap10_forward_head(x[0], fc, xre, xim, tau);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < K1; r++) {
+            const int row = (g + r) % K1;
+            const double* rre = lds_x + (size_t)row * BASE::GROUP_SLOTS;
+            swap10_forward_tail(x[r], rre, rre + BASE::PLANE, tau);
+        }
+        cplx outf[R];
+#pragma unroll
+        for (int r = 0; r < K1; r++) {
+#pragma unroll
+            for (int rho = 0; rho < R; rho++) {
+                const cplx bv = comb[r][rho], f = x[r][rho];
+                if (r == 0) {
+                    outf[rho].re = bv.re * f.re - bv.im * f.im;
+                    outf[rho].im = bv.re * f.im + bv.im * f.re;
+                } else {
+                    outf[rho].re = fma(bv.re, f.re, fma(-bv.im, f.im, outf[rho].re));
+                    outf[rho].im = fma(bv.re, f.im, fma(bv.im, f.re, outf[rho].im));
+                }
+            }
+        }
+        double* fre = lds_f + (size_t)g * BASE::GROUP_SLOTS;
+        double* fim = fre + BASE::PLANE;
+        swap10_inverse_head(outf, fre, fim, tau);
+        __syncthreads();
+        swap10_inverse_tail(outf, fc, fre, fim, tau);
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const cplx t = cmul_conj(outf[m], twist[m]);
+            acc_lo[m] = from_torus(t.re);                  // the destination was zero: no accumulate
+            acc_hi[m] = from_torus(t.im);
+        }
+    }
+
+    // sample extraction at degree 0 (glwe_sample_extraction.rs:121-146)
+    uint64_t* out = args.lwe_out + (size_t)sample * ((size_t)(K1 - 1) * N + 1);
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t j = PL::point(tau, m) + h * P;
+            const uint64_t v = h == 0 ? acc_lo[m] : acc_hi[m];
+            if (g == K1 - 1) {
+                if (j == 0) out[(size_t)(K1 - 1) * N] = v;
+            } else {
+                if (j == 0) out[(size_t)g * N] = v;
+                else out[(size_t)g * N + (N - j)] = 0 - v;
+            }
+        }
+    }
+}
+
+}  // namespace fhe

@@ -28,6 +28,7 @@ class _Params(C.Structure):
         ("ks_base_log", C.c_uint32), ("ks_level", C.c_uint32),
         ("msg_mod", C.c_uint32), ("carry_mod", C.c_uint32),
         ("lwe_std", C.c_double), ("glwe_std", C.c_double),
+        ("grouping_factor", C.c_uint32),
     ]
 
 
@@ -46,6 +47,12 @@ class Params:
     lwe_std: float
     glwe_std: float
     name: str = ""
+    grouping: int = 1          # multi-bit PBS grouping factor (1 = classic PBS)
+
+    @property
+    def n_ggsw(self) -> int:
+        """GGSWs in the bootstrapping key: n (classic) or n/g * 2^g (multi-bit)."""
+        return self.n if self.grouping <= 1 else self.n // self.grouping * (1 << self.grouping)
 
     @property
     def big_size(self) -> int:
@@ -69,11 +76,11 @@ class Params:
 
     @property
     def bsk_len(self) -> int:
-        return self.n * self.pbs_level * (self.k + 1) ** 2 * self.N
+        return self.n_ggsw * self.pbs_level * (self.k + 1) ** 2 * self.N
 
     def c(self) -> _Params:
         return _Params(self.n, self.k, self.N, self.pbs_base_log, self.pbs_level, self.ks_base_log,
-                       self.ks_level, self.msg_mod, self.carry_mod, self.lwe_std, self.glwe_std)
+                       self.ks_level, self.msg_mod, self.carry_mod, self.lwe_std, self.glwe_std, self.grouping)
 
 
 # reference: tfhe/src/shortint/parameters/mod.rs:703-717, :658-672, :613-627
@@ -83,6 +90,10 @@ PARAM_MESSAGE_2_CARRY_2_KS_PBS = Params(742, 1, 2048, 23, 1, 3, 5, 4, 4,
 PARAM_MESSAGE_4_CARRY_4_KS_PBS = Params(996, 1, 32768, 15, 2, 3, 7, 16, 16,
                                         6.767666038309478e-08, 2.168404344971009e-19,
                                         "PARAM_MESSAGE_4_CARRY_4_KS_PBS")
+# shortint/parameters/multi_bit.rs:115-135
+PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS = Params(818, 1, 2048, 22, 1, 5, 3, 4, 4,
+                                                          0.000002226459789930014, 0.0000000000000003152931493498455,
+                                                          "PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS", 2)
 PARAM_MESSAGE_2_CARRY_1_KS_PBS = Params(742, 2, 1024, 23, 1, 4, 3, 4, 2,
                                         0.000007069849454709433, 0.00000000000000029403601535432533,
                                         "PARAM_MESSAGE_2_CARRY_1_KS_PBS")

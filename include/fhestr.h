@@ -31,13 +31,18 @@
 extern "C" {
 #endif
 
-/* shortint/parameters/mod.rs:61-76 (ClassicPBSParameters; native modulus 2^64, KS->PBS order) */
+/* shortint/parameters/mod.rs:61-76 (ClassicPBSParameters) and multi_bit.rs (MultiBitPBSParameters);
+ * native modulus 2^64, KS->PBS order */
 typedef struct fhe_params_t {
     uint32_t n, k, N;
     uint32_t pbs_base_log, pbs_level;
     uint32_t ks_base_log, ks_level;
     uint32_t msg_mod, carry_mod;
     double lwe_std, glwe_std;
+    /* 0 or 1: classic PBS.  2: multi-bit PBS with that grouping factor (shortint/parameters/multi_bit.rs,
+     * core_crypto/algorithms/lwe_multi_bit_programmable_bootstrapping.rs): the bootstrapping key is then
+     * n/g * 2^g GGSWs, standard layout [group][selector][level][row][col][N]. */
+    uint32_t grouping_factor;
 } fhe_params_t;
 
 typedef struct fhe_engine fhe_engine;

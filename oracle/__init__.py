@@ -9,6 +9,7 @@ only marshals numpy arrays.
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 import os
 import subprocess
 from dataclasses import dataclass
@@ -113,6 +114,13 @@ TOY_SHAPES = [
     Params(3, 1, 32768, 11, 3, 3, 7, 8, 32, 1e-13, 1e-17, "TOY_N32768_L3"),   # 3_CARRY_5
 ]
 
+# multi-bit PBS parameter sets (shortint/parameters/multi_bit.rs:115-135): same fields + grouping factor
+PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS = Params(818, 1, 2048, 22, 1, 5, 3, 4, 4,
+                                                          0.000002226459789930014, 0.0000000000000003152931493498455,
+                                                          "PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS")
+TOY_MULTI_BIT_N2048 = Params(12, 1, 2048, 22, 1, 5, 3, 4, 4, 1e-13, 1e-17, "TOY_MULTI_BIT_N2048_G2")
+TOY_MULTI_BIT_N256 = Params(16, 1, 256, 10, 2, 4, 4, 4, 4, 1e-12, 1e-15, "TOY_MULTI_BIT_N256_G2")
+
 _u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -167,6 +175,9 @@ def lib() -> C.CDLL:
     sig("orc_gen_bsk", None, P, _u64p, _u64p, u64, _u64p, i32)
     sig("orc_encode", u64, P, u64)
     sig("orc_decode", u64, P, u64)
+    sig("orc_multi_bit_key_bits", None, _u64p, u32, u32, _u64p)
+    sig("orc_multi_bit_pbs_fft", None, P, u32, vp, _f64p, _u64p, _u64p, _u64p)
+    sig("orc_multi_bit_pbs_exact", None, P, u32, _u64p, _u64p, _u64p, _u64p)
     sig("orc_rng_init", None, vp, u64, u64)
     sig("orc_rng_next", u64, vp)
     _lib = L
@@ -357,6 +368,52 @@ class ServerKey:
 
     def trivial_pbs_body(self, body: int, lut) -> int:
         return int(lib().orc_trivial_pbs_body(C.byref(self.params.c()), int(body), _a(lut)))
+
+
+class MultiBitServerKey:
+    """Oracle twin of a shortint ServerKey holding a multi-bit bootstrapping key
+    (ShortintBootstrappingKey::MultiBit, shortint/server_key/mod.rs:829-851): KSK + the n/g * 2^g
+    GGSWs of lwe_multi_bit_bootstrap_key_generation.rs:87-173, standard and Fourier."""
+
+    def __init__(self, ck: ClientKey, grouping: int = 2, threads: int | None = None):
+        p = ck.params
+        assert p.n % grouping == 0
+        self.params, self.grouping = p, grouping
+        self.threads = threads or min(8, os.cpu_count() or 1)
+        self.n_ggsw = p.n // grouping * (1 << grouping)
+        self.key_bits = np.zeros(self.n_ggsw, dtype=np.uint64)
+        lib().orc_multi_bit_key_bits(ck.small_sk, p.n, grouping, self.key_bits)
+        self.ksk = np.zeros(p.big_dim * p.ks_level * p.small_size, dtype=np.uint64)
+        lib().orc_gen_ksk(C.byref(p.c()), ck.big_sk, ck.small_sk, ck.seed, self.ksk)
+        # the multi-bit key is a list of n_ggsw constant GGSWs: the classic generator on that list
+        self._pk = dataclasses.replace(p, n=self.n_ggsw)
+        self.bsk = np.zeros(self.n_ggsw * p.pbs_level * (p.k + 1) ** 2 * p.N, dtype=np.uint64)
+        lib().orc_gen_bsk(C.byref(self._pk.c()), self.key_bits, ck.glwe_sk, ck.seed, self.bsk, self.threads)
+        self.fbsk = np.zeros(self.bsk.size, dtype=np.float64)
+        lib().orc_bsk_to_fourier(C.byref(self._pk.c()), self.bsk, self.fbsk)
+        self._fft = lib().orc_fft_new(p.N)
+
+    generate_lookup_table = ServerKey.generate_lookup_table
+
+    def keyswitch(self, ct):
+        out = np.zeros(self.params.small_size, dtype=np.uint64)
+        lib().orc_keyswitch(C.byref(self.params.c()), self.ksk, _a(ct), out)
+        return out
+
+    def pbs(self, ct_small, lut, exact=False):
+        out = np.zeros(self.params.big_size, dtype=np.uint64)
+        if exact:
+            lib().orc_multi_bit_pbs_exact(C.byref(self.params.c()), self.grouping, self.bsk, _a(ct_small), _a(lut), out)
+        else:
+            lib().orc_multi_bit_pbs_fft(C.byref(self.params.c()), self.grouping, self._fft, self.fbsk,
+                                        _a(ct_small), _a(lut), out)
+        return out
+
+    def apply_lookup_table(self, ct, lut, exact=False):
+        return self.pbs(self.keyswitch(ct), lut, exact=exact)
+
+    def apply_lookup_table_batch(self, cts, lut, exact=False):
+        return np.stack([self.apply_lookup_table(c, lut, exact=exact) for c in _a(cts).reshape(-1, self.params.big_size)])
 
 
 def fft_roundtrip_product(N: int, torus_poly, int_poly):

@@ -511,6 +511,117 @@ void orc_pbs_exact(const orc_params *p, const uint64_t *bsk_std, const uint64_t 
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Multi-bit PBS (grouping factor g): core_crypto/algorithms/lwe_multi_bit_programmable_bootstrapping.rs
+ * The key holds, per group of g consecutive secret bits, 2^g GGSWs; GGSW number `sel` encrypts the
+ * product over the group's bits of (s_b if bit b of sel is set else 1 - s_b), most significant
+ * selector bit = first key bit (lwe_multi_bit_bootstrap_key_generation.rs:401-427), so the
+ * standard-domain key is a plain list of n/g * 2^g constant GGSWs and reuses every classic routine.
+ * ---------------------------------------------------------------------------------------- */
+/* plaintext of GGSW `sel` of a group (combine_key_bits) */
+static uint64_t combine_key_bits(uint32_t sel, const uint64_t *bits, uint32_t g) {
+    uint64_t prod = 1;
+    for (uint32_t b = 0; b < g; b++) {
+        uint32_t pos = g - (b + 1);
+        uint64_t inversion = ((sel >> pos) & 1) ^ 1;
+        prod *= bits[b] ^ inversion;
+    }
+    return prod;
+}
+/* the n/g * 2^g plaintext bits the multi-bit key's GGSWs encrypt, in key order */
+void orc_multi_bit_key_bits(const uint64_t *small_sk, uint32_t n, uint32_t g, uint64_t *out) {
+    for (uint32_t grp = 0; grp < n / g; grp++)
+        for (uint32_t sel = 0; sel < (1u << g); sel++)
+            out[(size_t)grp * (1u << g) + sel] = combine_key_bits(sel, small_sk + (size_t)grp * g, g);
+}
+
+/* prepare_multi_bit_ggsw (:18-83) + one external product per group (:497-523, deterministic order
+ * :548-).  fbsk / bsk_std: Fourier or standard key as produced by orc_bsk_to_fourier / orc_gen_bsk on
+ * the n/g * 2^g GGSW list.  Exactly one of (f, fbsk) / bsk_std is used. */
+static void multi_bit_blind_rotate(const orc_params *p, uint32_t g, const orc_fft *f, const double *fbsk,
+                                   const uint64_t *bsk_std, const uint64_t *lwe, uint64_t *acc) {
+    const uint32_t N = p->N, k1 = p->k + 1, n = p->n;
+    const size_t G = (size_t)k1 * N;
+    const uint32_t logN = ilog2(N);
+    const size_t ggsw_polys = (size_t)p->pbs_level * k1 * k1, ggsw_len = ggsw_polys * N;
+    const uint32_t per_group = 1u << g;
+    uint64_t *tmp = (uint64_t *)malloc(G * sizeof(uint64_t));
+    uint64_t deg0 = orc_modulus_switch(lwe[n], logN);
+    for (uint32_t q = 0; q < k1; q++) {
+        memcpy(tmp, acc + (size_t)q * N, N * sizeof(uint64_t));
+        orc_monomial_div(acc + (size_t)q * N, tmp, N, deg0, 64);
+    }
+    double *comb_f = fbsk ? (double *)malloc(ggsw_len * sizeof(double)) : NULL;
+    double *mono_f = fbsk ? (double *)malloc((size_t)N * sizeof(double)) : NULL;
+    uint64_t *comb_s = fbsk ? NULL : (uint64_t *)malloc(ggsw_len * sizeof(uint64_t));
+    uint64_t *mono = (uint64_t *)malloc((size_t)N * sizeof(uint64_t));
+    uint64_t *poly = (uint64_t *)malloc((size_t)N * sizeof(uint64_t));
+    for (uint32_t grp = 0; grp < n / g; grp++) {
+        const uint64_t *mask = lwe + (size_t)grp * g;
+        const size_t base = (size_t)grp * per_group;
+        /* the first GGSW of a group encrypts the constant term: copied as is (:36-47) */
+        if (fbsk) memcpy(comb_f, fbsk + base * ggsw_len, ggsw_len * sizeof(double));
+        else memcpy(comb_s, bsk_std + base * ggsw_len, ggsw_len * sizeof(uint64_t));
+        for (uint32_t sel = 1; sel < per_group; sel++) {
+            uint64_t degree = 0; /* :57-64 wrapping sum of the selected mask elements, THEN switched */
+            for (uint32_t b = 0; b < g; b++) {
+                uint32_t pos = g - (b + 1);
+                if ((sel >> pos) & 1) degree += mask[b];
+            }
+            uint64_t sw = orc_modulus_switch(degree, logN);
+            if (fbsk) {
+                memset(mono, 0, (size_t)N * sizeof(uint64_t)); /* X^sw, X^N = -1 */
+                uint64_t r = sw % (2 * (uint64_t)N);
+                if (r < N) mono[r] = 1; else mono[r - N] = (uint64_t)0 - 1;
+                orc_fft_forward_as_integer(f, mono_f, mono);
+                const double *gs = fbsk + (base + sel) * ggsw_len;
+                for (size_t q = 0; q < ggsw_polys; q++) {
+                    double *o = comb_f + q * N;
+                    const double *gq = gs + q * N;
+                    for (uint32_t j = 0; j < N / 2; j++) { /* update_with_fmadd_factor (:73-81) */
+                        double gr = gq[2 * j], gi = gq[2 * j + 1], mr = mono_f[2 * j], mi = mono_f[2 * j + 1];
+                        o[2 * j] += gr * mr - gi * mi;
+                        o[2 * j + 1] += gr * mi + gi * mr;
+                    }
+                }
+            } else {
+                const uint64_t *gs = bsk_std + (base + sel) * ggsw_len;
+                for (size_t q = 0; q < ggsw_polys; q++) {
+                    orc_monomial_mul(poly, gs + q * N, N, sw, 64);
+                    uint64_t *o = comb_s + q * N;
+                    for (uint32_t c = 0; c < N; c++) o[c] += poly[c];
+                }
+            }
+        }
+        /* dst = 0; dst += combined (x) acc; acc = dst  (:497-523) */
+        memcpy(tmp, acc, G * sizeof(uint64_t));
+        memset(acc, 0, G * sizeof(uint64_t));
+        if (fbsk) orc_add_external_product_fft(p, f, acc, comb_f, tmp);
+        else orc_add_external_product_exact(p, acc, comb_s, tmp);
+    }
+    free(tmp); free(comb_f); free(mono_f); free(comb_s); free(mono); free(poly);
+}
+
+/* multi_bit_programmable_bootstrap_lwe_ciphertext (:1035-1127): copy LUT, blind rotate, extract */
+void orc_multi_bit_pbs_fft(const orc_params *p, uint32_t g, const orc_fft *f, const double *fbsk,
+                           const uint64_t *lwe, const uint64_t *lut, uint64_t *out) {
+    size_t G = (size_t)(p->k + 1) * p->N;
+    uint64_t *acc = (uint64_t *)malloc(G * sizeof(uint64_t));
+    memcpy(acc, lut, G * sizeof(uint64_t));
+    multi_bit_blind_rotate(p, g, f, fbsk, NULL, lwe, acc);
+    orc_sample_extract(p, acc, out);
+    free(acc);
+}
+void orc_multi_bit_pbs_exact(const orc_params *p, uint32_t g, const uint64_t *bsk_std, const uint64_t *lwe,
+                             const uint64_t *lut, uint64_t *out) {
+    size_t G = (size_t)(p->k + 1) * p->N;
+    uint64_t *acc = (uint64_t *)malloc(G * sizeof(uint64_t));
+    memcpy(acc, lut, G * sizeof(uint64_t));
+    multi_bit_blind_rotate(p, g, NULL, NULL, bsk_std, lwe, acc);
+    orc_sample_extract(p, acc, out);
+    free(acc);
+}
+
+/* ------------------------------------------------------------------------------------------
  * shortint/server_key/mod.rs:783-857 (keyswitch_programmable_bootstrap_assign), batched the way
  * benches/core_crypto/pbs_bench.rs:517-532 does it: independent LWEs over worker threads.
  * ---------------------------------------------------------------------------------------- */

@@ -94,6 +94,13 @@ void orc_pbs_exact(const orc_params *p, const uint64_t *bsk_std, const uint64_t 
 /* shortint apply_lookup_table on a batch (KS -> PBS), `threads` OS threads over LWEs.
  * luts: n_luts*(k+1)*N, lut_idx: per-LWE index (NULL => 0). exact != 0 selects the exact
  * integer external product (bsk_std used), else the f64 FFT one (fbsk used). */
+/* multi-bit PBS (lwe_multi_bit_programmable_bootstrapping.rs); keys = classic routines run on the
+ * n/g * 2^g GGSW list whose plaintext bits orc_multi_bit_key_bits returns */
+void orc_multi_bit_key_bits(const uint64_t *small_sk, uint32_t n, uint32_t g, uint64_t *out);
+void orc_multi_bit_pbs_fft(const orc_params *p, uint32_t g, const orc_fft *f, const double *fbsk,
+                           const uint64_t *lwe, const uint64_t *lut, uint64_t *out);
+void orc_multi_bit_pbs_exact(const orc_params *p, uint32_t g, const uint64_t *bsk_std, const uint64_t *lwe,
+                             const uint64_t *lut, uint64_t *out);
 void orc_ks_pbs_batch(const orc_params *p, const uint64_t *ksk, const double *fbsk,
                       const uint64_t *bsk_std, int exact, const uint64_t *lwe_in,
                       const uint32_t *lut_idx, const uint64_t *luts, uint64_t *lwe_out,

@@ -1,0 +1,24 @@
+"""PBS/s of the multi-bit PBS (PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS) next to the classic one
+(PARAM_MESSAGE_2_CARRY_2_KS_PBS): device-generated keys, decrypt-checked."""
+import sys, time
+import numpy as np
+sys.path.insert(0, "fhe-string-bounty_amd")
+import fhestr
+
+for P in (fhestr.PARAM_MESSAGE_2_CARRY_2_KS_PBS, fhestr.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS):
+    ck = fhestr.ClientKey(P, 0x5EED0002)
+    g, s = ck.secret_keys()
+    eng = fhestr.Engine(P, 0)
+    eng.generate_keys(g, s, 0x5EED0002)
+    lut, _ = eng.generate_lookup_table(lambda x: (x * x + 1) % 16)
+    rng = np.random.default_rng(3)
+    for B in (1, 64, 256, 1024, 4096):
+        msgs = rng.integers(0, 16, size=B)
+        cts = ck.encrypt(msgs)
+        idx = np.full(B, lut, dtype=np.uint32)
+        out = eng.apply_lookup_table(cts, idx)
+        ok = np.array_equal(ck.decrypt(out), (msgs * msgs + 1) % 16)
+        eng.apply_lookup_table(cts, idx)
+        ks, br = eng.last_kernel_ms()
+        print(f"{P.name} B={B}: keyswitch {ks:.3f} ms, blind rotation {br:.3f} ms -> {B / ((ks + br) * 1e-3):.0f} PBS/s (kernels), correct {ok}", flush=True)
+    eng.close()
