@@ -123,49 +123,18 @@ blind_rotate_multibit_kernel(BlindRotateArgs args) {
     constexpr size_t GGSW_ELEMS = (size_t)K1 * K1 * P;
 
     for (uint32_t grp = 0; grp < groups; grp++) {
-        // ---- this group's GGSW, column g, rows (g + r) % K1: G0 + sum_sel G_sel * monomial_sel ----
+        // ---- request this group's 2^G GGSWs (column g, rows (g + r) % K1) now: they arrive from L2
+        //      while the accumulator is decomposed and transformed ----
         const double2* gk = fbsk + (size_t)grp * (SEL + 1) * GGSW_ELEMS;
-        cplx comb[K1][R];
+        double2 gv[SEL + 1][K1][R];
 #pragma unroll
-        for (int r = 0; r < K1; r++) {
-            const int row = (g + r) % K1;
-#pragma unroll
-            for (int rho = 0; rho < R; rho++) {
-                const double2 v = gk[((size_t)row * K1 + g) * P + rho * T + tau];
-                comb[r][rho].re = v.x; comb[r][rho].im = v.y;
-            }
-        }
-#pragma unroll
-        for (int s = 1; s <= SEL; s++) {
-            const uint32_t d = lds_deg[grp * SEL + (s - 1)];
-            const double2* gs = gk + (size_t)s * GGSW_ELEMS;
-            double2 gv[K1][R];
+        for (int s = 0; s <= SEL; s++) {
 #pragma unroll
             for (int r = 0; r < K1; r++) {
                 const int row = (g + r) % K1;
 #pragma unroll
-                for (int rho = 0; rho < R; rho++) gv[r][rho] = gs[((size_t)row * K1 + g) * P + rho * T + tau];
-            }
-            // monomial transform at slot rho: w^{d (1 - 4 f_tau)} * (-i)^{d rho}
-            const uint32_t mi = (d * c_tau) & (2u * N - 1u);
-            const double2 a = root_lo[mi & ((1u << CFG::ROOT_LO_BITS) - 1u)], b = root_hi[mi >> CFG::ROOT_LO_BITS];
-            cplx mono;
-            mono.re = a.x * b.x - a.y * b.y;
-            mono.im = a.x * b.y + a.y * b.x;
-            // (-i)^d as a complex number with entries in {0, +-1}
-            const int q = d & 3;
-            cplx turn;
-            turn.re = q == 0 ? 1.0 : q == 2 ? -1.0 : 0.0;
-            turn.im = q == 1 ? -1.0 : q == 3 ? 1.0 : 0.0;
-#pragma unroll
-            for (int rho = 0; rho < R; rho++) {
-#pragma unroll
-                for (int r = 0; r < K1; r++) {
-                    const double2 v = gv[r][rho];
-                    comb[r][rho].re = fma(v.x, mono.re, fma(-v.y, mono.im, comb[r][rho].re));
-                    comb[r][rho].im = fma(v.x, mono.im, fma(v.y, mono.re, comb[r][rho].im));
-                }
-                mono = cmul(mono, turn);
+                for (int rho = 0; rho < R; rho++)
+                    gv[s][r][rho] = gk[(size_t)s * GGSW_ELEMS + ((size_t)row * K1 + g) * P + rho * T + tau];
             }
         }
 
@@ -186,6 +155,39 @@ blind_rotate_multibit_kernel(BlindRotateArgs args) {
             const double* rre = lds_x + (size_t)row * BASE::GROUP_SLOTS;
             swap10_forward_tail(x[r], rre, rre + BASE::PLANE, tau);
         }
+
+        // ---- the group's GGSW: G0 + sum_sel G_sel * monomial_sel (prepare_multi_bit_ggsw, :18-83) ----
+        cplx comb[K1][R];
+#pragma unroll
+        for (int r = 0; r < K1; r++)
+#pragma unroll
+            for (int rho = 0; rho < R; rho++) { comb[r][rho].re = gv[0][r][rho].x; comb[r][rho].im = gv[0][r][rho].y; }
+#pragma unroll
+        for (int s = 1; s <= SEL; s++) {
+            const uint32_t d = lds_deg[grp * SEL + (s - 1)];
+            // monomial transform at slot rho: w^{d (1 - 4 f_tau)} * (-i)^{d rho}
+            const uint32_t mi = (d * c_tau) & (2u * N - 1u);
+            const double2 a = root_lo[mi & ((1u << CFG::ROOT_LO_BITS) - 1u)], b = root_hi[mi >> CFG::ROOT_LO_BITS];
+            cplx mono;
+            mono.re = a.x * b.x - a.y * b.y;
+            mono.im = a.x * b.y + a.y * b.x;
+            // (-i)^d as a complex number with entries in {0, +-1}
+            const int q = d & 3;
+            cplx turn;
+            turn.re = q == 0 ? 1.0 : q == 2 ? -1.0 : 0.0;
+            turn.im = q == 1 ? -1.0 : q == 3 ? 1.0 : 0.0;
+#pragma unroll
+            for (int rho = 0; rho < R; rho++) {
+#pragma unroll
+                for (int r = 0; r < K1; r++) {
+                    const double2 v = gv[s][r][rho];
+                    comb[r][rho].re = fma(v.x, mono.re, fma(-v.y, mono.im, comb[r][rho].re));
+                    comb[r][rho].im = fma(v.x, mono.im, fma(v.y, mono.re, comb[r][rho].im));
+                }
+                mono = cmul(mono, turn);
+            }
+        }
+
         cplx outf[R];
 #pragma unroll
         for (int r = 0; r < K1; r++) {

@@ -27,7 +27,7 @@
     } while (0)
 
 static const fhe_params_t P22 = {742, 1, 2048, 23, 1, 3, 5, 4, 4, 0.000007069849454709433,
-                                 0.00000000000000029403601535432533};
+                                 0.00000000000000029403601535432533, 0 /* classic PBS */};
 enum { M = 16, MSG = 4 };
 
 static uint64_t twice(uint64_t x) { return (x * 2) % MSG; }
