@@ -1,3 +1,4 @@
+#include <algorithm>
 // c_api.cpp -- extern "C" boundary (include/fhestr.h).  Mirrors the reference C API conventions:
 // every entry point catches everything and returns 0/1 (c_api/utils.rs:3-12), out-pointers are
 // nulled first so unchecked failures are loud (c_api/shortint/server_key/pbs.rs:24-29).
@@ -36,6 +37,7 @@ int fhe_engine_create(const fhe_params_t* params, int device, fhe_engine** out) 
 int fhe_engine_destroy(fhe_engine* eng) {
     API_BEGIN
     if (!eng) return 0;
+    for (auto& kv : eng->str_plans) fhe_plan_destroy(kv.second);
     delete eng->impl;
     delete eng;
     return 0;
@@ -416,16 +418,30 @@ static int str_op(fhe_engine* eng, const char* op, const uint64_t* a, uint32_t a
                   uint32_t b_cap, const uint8_t* clear, uint32_t clear_len, uint64_t* out) {
     API_BEGIN
     CHECK_PTR(eng); CHECK_PTR(a); CHECK_PTR(out);
+    // plan cache, most recently used first (at most STR_PLAN_CACHE entries)
+    constexpr size_t STR_PLAN_CACHE = 8;
+    std::string key = std::string(op) + "|" + std::to_string(a_cap) + "|" + std::to_string(b_cap) + "|";
+    if (clear) key.append(reinterpret_cast<const char*>(clear), clear_len);
     fhe_plan* plan = nullptr;
-    if (fhe_str_plan_create(eng, op, a_cap, b_cap, clear, clear_len, 1, &plan)) return 1;
-    const size_t big = (size_t)eng->impl->p.k * eng->impl->p.N + 1;
-    std::vector<uint64_t> in((size_t)plan->c->n_inputs() * big);
-    const uint32_t bpc = plan->c->n_inputs() / (a_cap + (b ? b_cap : 0));
-    std::copy(a, a + (size_t)a_cap * bpc * big, in.begin());
-    if (b) std::copy(b, b + (size_t)b_cap * bpc * big, in.begin() + (size_t)a_cap * bpc * big);
-    int rc = plan->c->run_host(in.data(), out);
-    fhe_plan_destroy(plan);
-    return rc;
+    auto& cache = eng->str_plans;
+    for (size_t i = 0; i < cache.size(); i++)
+        if (cache[i].first == key) {
+            plan = cache[i].second;
+            std::rotate(cache.begin(), cache.begin() + i, cache.begin() + i + 1);
+            break;
+        }
+    if (!plan) {
+        if (fhe_str_plan_create(eng, op, a_cap, b_cap, clear, clear_len, 1, &plan)) return 1;
+        cache.insert(cache.begin(), {key, plan});
+        if (cache.size() > STR_PLAN_CACHE) {
+            fhe_plan_destroy(cache.back().second);
+            cache.pop_back();
+        }
+    }
+    const uint32_t bpc = plan->c->n_inputs() / (a_cap + (b ? b_cap : 0));      // blocks per character
+    const uint64_t* parts[2] = {a, b};
+    const uint32_t counts[2] = {a_cap * bpc, b ? b_cap * bpc : 0};
+    return plan->c->run_host_parts(parts, counts, 2, out);
     API_END
 }
 

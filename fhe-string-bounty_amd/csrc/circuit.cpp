@@ -239,14 +239,29 @@ int Circuit::gather_outputs(const uint64_t* d_pool, uint64_t* d_out) {
 }
 
 int Circuit::run_host(const uint64_t* inputs, uint64_t* outputs) {
+    const uint64_t* parts[1] = {inputs};
+    const uint32_t counts[1] = {n_inputs_};
+    return run_host_parts(parts, counts, 1, outputs);
+}
+
+// Inputs given as several host arrays (e.g. the two operands of a string comparison) that together
+// hold n_inputs LWEs: each goes to the device pool directly, no staging copy on the host.
+int Circuit::run_host_parts(const uint64_t* const* parts, const uint32_t* counts, uint32_t n_parts, uint64_t* outputs) {
     if (!eng_) return fail("offline plan: no engine bound (there is no CPU execution path)");
     if (eng_->use()) return 1;
     if (world_ != 1) return fail("run_host needs a plan finalised for world = 1");
     const size_t big = (size_t)p_.k * p_.N + 1;
     if (!d_own_pool_) HIP_TRY(hipMalloc((void**)&d_own_pool_, (size_t)std::max<uint32_t>(pool_slots_, 1) * big * 8));
     if (!d_own_out_) HIP_TRY(hipMalloc((void**)&d_own_out_, (size_t)std::max<uint32_t>(n_outputs(), 1) * big * 8));
-    if (n_inputs_)
-        HIP_TRY(hipMemcpyAsync(d_own_pool_, inputs, (size_t)n_inputs_ * big * 8, hipMemcpyHostToDevice, eng_->stream));
+    uint32_t placed = 0;
+    for (uint32_t i = 0; i < n_parts; i++) {
+        if (!counts[i]) continue;
+        if (placed + counts[i] > n_inputs_) return fail("run_host: more input LWEs than the plan has inputs");
+        HIP_TRY(hipMemcpyAsync(d_own_pool_ + (size_t)placed * big, parts[i], (size_t)counts[i] * big * 8,
+                               hipMemcpyHostToDevice, eng_->stream));
+        placed += counts[i];
+    }
+    if (placed != n_inputs_) return fail("run_host: fewer input LWEs than the plan has inputs");
     for (uint32_t l = 0; l < levels_.size(); l++)
         if (run_level_slice(d_own_pool_, l, 0, (uint32_t)levels_[l].jobs.size())) return 1;
     if (gather_outputs(d_own_pool_, d_own_out_)) return 1;

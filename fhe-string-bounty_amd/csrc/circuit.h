@@ -104,7 +104,8 @@ public:
     int upload_meta();
     int run_level_slice(uint64_t* d_pool, uint32_t level, uint32_t lo, uint32_t hi);
     int gather_outputs(const uint64_t* d_pool, uint64_t* d_out);
-    int run_host(const uint64_t* inputs, uint64_t* outputs);     // single GPU, host buffers
+    int run_host(const uint64_t* inputs, uint64_t* outputs);
+    int run_host_parts(const uint64_t* const* parts, const uint32_t* counts, uint32_t n_parts, uint64_t* outputs);     // single GPU, host buffers
     ~Circuit();
 
 private:

@@ -94,6 +94,10 @@ struct Engine {
 
 }  // namespace fhe
 
+struct fhe_plan;
 struct fhe_engine {
     fhe::Engine* impl;
+    // plans of the one-call string operations (fhe_str_eq ...), most recently used first: building a
+    // plan and allocating its pool costs milliseconds, the same (op, capacities, clear pattern) recurs
+    std::vector<std::pair<std::string, fhe_plan*>> str_plans;
 };
