@@ -414,7 +414,10 @@ __device__ __forceinline__ void swap10_twiddle(cplx* x, const cplx* tw) {
 // Forward transform in two halves around its one workgroup barrier.
 //   head: passes 1-4 of this thread's polynomial, left in the slab side of the (re, im) planes
 //   tail: after the barrier, the comb side of ANY polynomial's planes -> last pass -> x[rho]
-__device__ __forceinline__ void swap10_forward_head(cplx* x, const FftConsts<FftSwap10>& c, double* re, double* im, int tau) {
+// The head in three stages separated by the wave-local fences, so that callers carrying several
+// polynomials per thread can run stage by stage over all of them (one polynomial's LDS round trip
+// then hides behind the other's butterflies).
+__device__ __forceinline__ void swap10_fwd_stage1(cplx* x, const FftConsts<FftSwap10>& c, double* re, double* im, int tau) {
     small_dft<4, false>(x);
     swap10_twiddle<false>(x, c.tw[0]);
     swap_regs_lanes(x);
@@ -427,20 +430,29 @@ __device__ __forceinline__ void swap10_forward_head(cplx* x, const FftConsts<Fft
         const int a = swap10_side_a(tau, r); re[a] = x[r].re; im[a] = x[r].im;
         FHE_PIN_ORDER();
     }
-    wave_local_fence();
+}
+__device__ __forceinline__ void swap10_fwd_stage2(cplx* x, const FftConsts<FftSwap10>& c, const double* re, const double* im, int tau) {
 #pragma unroll
     for (int r = 0; r < 4; r++) { const int a = swap10_side_b(tau, r); x[r].re = re[a]; x[r].im = im[a]; }
     small_dft<4, false>(x);
     swap10_twiddle<false>(x, c.tw[2]);
     swap_regs_lanes(x);
     small_dft<4, false>(x);
-    wave_local_fence();          // the slab stores below reuse the rows the exchange above read
+}
+__device__ __forceinline__ void swap10_fwd_stage3(cplx* x, const FftConsts<FftSwap10>& c, double* re, double* im, int tau) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         if (r) x[r] = cmul(x[r], c.tw[3][r]);
         const int a = swap10_slab(tau, r); re[a] = x[r].re; im[a] = x[r].im;
         FHE_PIN_ORDER();
     }
+}
+__device__ __forceinline__ void swap10_forward_head(cplx* x, const FftConsts<FftSwap10>& c, double* re, double* im, int tau) {
+    swap10_fwd_stage1(x, c, re, im, tau);
+    wave_local_fence();
+    swap10_fwd_stage2(x, c, re, im, tau);
+    wave_local_fence();          // the slab stores below reuse the rows the exchange above read
+    swap10_fwd_stage3(x, c, re, im, tau);
 }
 __device__ __forceinline__ void swap10_forward_tail(cplx* x, const double* re, const double* im, int tau) {
 #pragma unroll
@@ -454,19 +466,21 @@ __device__ __forceinline__ void swap10_inverse_head(const cplx* x, double* re, d
         FHE_PIN_ORDER();
     });
 }
-__device__ __forceinline__ void swap10_inverse_tail(cplx* x, const FftConsts<FftSwap10>& c, double* re, double* im, int tau) {
+__device__ __forceinline__ void swap10_inv_stage1(cplx* x, const FftConsts<FftSwap10>& c, const double* re, const double* im, int tau) {
 #pragma unroll
     for (int r = 0; r < 4; r++) { const int a = swap10_slab(tau, r); x[r].re = re[a]; x[r].im = im[a]; }
     swap10_twiddle<true>(x, c.tw[3]);
     small_dft<4, true>(x);
     swap_regs_lanes(x);
     swap10_twiddle<true>(x, c.tw[2]);
-    wave_local_fence();          // the exchange below reuses the slab rows just read
+}
+__device__ __forceinline__ void swap10_inv_stage2(const cplx* x, double* re, double* im, int tau) {
     dft4_emit<true>(x, [&](int r, cplx y) {
         const int a = swap10_side_b(tau, r); re[a] = y.re; im[a] = y.im;
         FHE_PIN_ORDER();
     });
-    wave_local_fence();
+}
+__device__ __forceinline__ void swap10_inv_stage3(cplx* x, const FftConsts<FftSwap10>& c, const double* re, const double* im, int tau) {
 #pragma unroll
     for (int r = 0; r < 4; r++) { const int a = swap10_side_a(tau, r); x[r].re = re[a]; x[r].im = im[a]; }
     swap10_twiddle<true>(x, c.tw[1]);
@@ -475,6 +489,13 @@ __device__ __forceinline__ void swap10_inverse_tail(cplx* x, const FftConsts<Fft
     swap10_twiddle<true>(x, c.tw[0]);
     small_dft<4, true>(x);
 }
+__device__ __forceinline__ void swap10_inverse_tail(cplx* x, const FftConsts<FftSwap10>& c, double* re, double* im, int tau) {
+    swap10_inv_stage1(x, c, re, im, tau);
+    wave_local_fence();          // the exchange below reuses the slab rows just read
+    swap10_inv_stage2(x, re, im, tau);
+    wave_local_fence();
+    swap10_inv_stage3(x, c, re, im, tau);
+}
 
 // NPOLY polynomials carried by the same threads (planes of polynomial p at re0 + p*poly_stride,
 // imaginary plane im_off slots further): one workgroup barrier serves all of them.
@@ -482,7 +503,13 @@ template <int NPOLY>
 __device__ __forceinline__ void swap10_forward(cplx (*x)[4], const FftConsts<FftSwap10>& c, double* re0,
                                                int poly_stride, int im_off, int tau) {
 #pragma unroll
-    for (int p = 0; p < NPOLY; p++) swap10_forward_head(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    for (int p = 0; p < NPOLY; p++) swap10_fwd_stage1(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    wave_local_fence();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap10_fwd_stage2(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    wave_local_fence();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap10_fwd_stage3(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < NPOLY; p++) swap10_forward_tail(x[p], re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
@@ -494,7 +521,13 @@ __device__ __forceinline__ void swap10_inverse(cplx (*x)[4], const FftConsts<Fft
     for (int p = 0; p < NPOLY; p++) swap10_inverse_head(x[p], re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < NPOLY; p++) swap10_inverse_tail(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    for (int p = 0; p < NPOLY; p++) swap10_inv_stage1(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    wave_local_fence();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap10_inv_stage2(x[p], re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    wave_local_fence();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap10_inv_stage3(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
 }
 
 // Forward transform.  In: x[m] = point (tau + T*m) of the (already twisted) input.
