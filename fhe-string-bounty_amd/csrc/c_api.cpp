@@ -29,7 +29,7 @@ int fhe_engine_create(const fhe_params_t* params, int device, fhe_engine** out) 
     CHECK_PTR(params);
     fhe::Engine* e = nullptr;
     if (fhe::Engine::create(*params, device, &e)) return 1;
-    *out = new fhe_engine{e};
+    *out = new fhe_engine{e, {}};
     return 0;
     API_END
 }
