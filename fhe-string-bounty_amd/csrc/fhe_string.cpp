@@ -730,6 +730,9 @@ int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t 
                 const uint32_t both = c.lut_fn([](uint64_t x) { return (uint64_t)(x == 1); });
                 for (uint32_t o = 1; o < match.size(); o++)
                     match[o] = c.pbs(c.lin({{match[o], 1}, {s.char_is_zero(a.ch[o - 1]), 2}}, 0, 3), both);
+                // ... and an empty pattern matches at offset cap when the string fills its capacity
+                // (bytes.rfind(b"") == len): pattern empty AND s[cap-1] != 0
+                match.push_back(c.pbs(c.lin({{s.char_is_zero(b.ch[0]), 1}, {s.char_is_zero(a.ch[a_cap - 1]), 2}}, 0, 3), both));
             }
         }
         std::vector<uint32_t> outs;

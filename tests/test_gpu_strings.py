@@ -274,3 +274,23 @@ def test_random_circuits_gpu_vs_clear_and_oracle(toy_k1, seed):
     got = _dec(toy_k1, plan.run(inputs)).tolist()
     assert got == evaluate(values)
     assert got == _dec(toy_k1, run_with_oracle(plan, inputs, toy_k1.sk)).tolist()
+
+
+def test_rfind_encrypted_empty_pattern_on_full_string(toy_k1):
+    """bytes.rfind(b"") == len(s), also when s fills its capacity and the pattern is encrypted (found by
+    scripts/fuzz_strings.py)."""
+    ops = _ops(toy_k1)
+    for s, cap in ((b"qy", 2), (b"BABx", 4), (b"ab", 4), (b"", 3)):
+        r = _dec(toy_k1, ops.rfind(_enc(toy_k1, s, cap), _enc(toy_k1, b"", 2)))
+        assert r[0] == 1 and sum(int(v) * 4 ** i for i, v in enumerate(r[1:])) == len(s)
+
+
+def test_fuzz_string_ops_against_python():
+    """scripts/fuzz_strings.py: random strings / patterns / operations vs Python bytes semantics."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_strings.py"), "400", "7"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
