@@ -467,6 +467,13 @@ STR_BINARY(lt)
 STR_BINARY(le)
 STR_BINARY(gt)
 STR_BINARY(ge)
+STR_BINARY(concat)
+
+int fhe_str_repeat_clear(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, uint32_t count, uint64_t* out) {
+    if (count == 0 || count > 255) return fail("repeat: count must be in 1..255");
+    const uint8_t c = (uint8_t)count;
+    return str_op(eng, "repeat_clear", a, a_cap, nullptr, 0, &c, 1, out);
+}
 
 int fhe_str_replace(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, const uint64_t* from_to,
                     uint32_t pat_cap, uint64_t* out) {

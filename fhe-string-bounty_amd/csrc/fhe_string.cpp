@@ -452,6 +452,12 @@ public:
         std::vector<uint32_t> seen = prefix_or(nws);           // seen[i] = some non-ws char in [0, i]
         std::vector<uint32_t> lead(s.cap);                     // lead[i] = chars 0..i all whitespace
         for (uint32_t i = 0; i < s.cap; i++) lead[i] = not_bit(seen[i]);
+        return shift_left_by_leading(s, lead);
+    }
+    // Shift `s` left by the number of leading ones of the monotone indicator lead (lead[i] = 1 for
+    // i < z, 0 after): barrel shifter, stage t shifts by 2^t iff lead[2^t - 1] (i.e. z >= 2^t), the
+    // indicator shifts along with the string.  (cmux per block: integer/server_key/radix_parallel/cmux.rs)
+    Str shift_left_by_leading(const Str& s, std::vector<uint32_t> lead) {
         Str cur = s;
         int top = 0;
         while ((1u << (top + 1)) <= s.cap) top++;
@@ -477,6 +483,35 @@ public:
             lead = nlead;
         }
         return cur;
+    }
+    // concat: a ++ b without a's padding.  b is parked behind a's full capacity and shifted left by the
+    // number of null characters at the end of a (monotone indicator read from the end of a); the result
+    // (capacity a.cap + b.cap) is a + shifted(b): wherever b lands, a is null.
+    Str concat(const Str& a, const Str& b) {
+        Str u;
+        u.cap = a.cap + b.cap;
+        u.ch.resize(u.cap);
+        const uint32_t zero = c.trivial(0);
+        for (uint32_t i = 0; i < a.cap; i++) u.ch[i].assign(bpc, zero);
+        for (uint32_t j = 0; j < b.cap; j++) u.ch[a.cap + j] = b.ch[j];
+        std::vector<uint32_t> lead(u.cap, zero);
+        for (uint32_t t = 0; t < a.cap; t++) lead[t] = char_is_zero(a.ch[a.cap - 1 - t]);   // 1 while still in a's padding
+        Str v = shift_left_by_leading(u, lead);
+        Str out;
+        out.cap = u.cap;
+        out.ch.resize(u.cap);
+        for (uint32_t i = 0; i < u.cap; i++)
+            for (uint32_t k = 0; k < bpc; k++)
+                out.ch[i].push_back(i < a.cap ? c.lin({{a.ch[i][k], 1}, {v.ch[i][k], 1}}, 0, M - 1) : v.ch[i][k]);
+        return out;
+    }
+    Str clear_string(const uint8_t* bytes, uint32_t len) {
+        Str t;
+        t.cap = len;
+        t.ch.resize(len);
+        for (uint32_t i = 0; i < len; i++)
+            for (uint32_t k = 0; k < bpc; k++) t.ch[i].push_back(c.trivial(clear_block(bytes[i], k)));
+        return t;
     }
 
     // ---- replace (equal-length pattern and replacement) ----
@@ -745,6 +780,16 @@ int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t 
             s.find_from_matches(match, n_digits, outs, from_end);
         }
         for (uint32_t o : outs) c.output(o);
+    } else if (base == "concat") {
+        // out capacity = a_cap + (b_cap | clear_len); clear right operand: "concat_clear"
+        if (is_clear && clear_len == 0) s.emit(a);
+        else s.emit(s.concat(a, is_clear ? s.clear_string(clear, clear_len) : b));
+    } else if (base == "repeat") {
+        // clear repetition count in clear[0] (>= 1): out capacity = count * a_cap
+        if (!is_clear || clear_len != 1 || clear[0] == 0) return fail("repeat_clear takes one clear byte: the count (>= 1)");
+        Str r = a;
+        for (uint32_t i = 1; i < clear[0]; i++) r = s.concat(r, a);
+        s.emit(r);
     } else if (base == "to_upper" || base == "to_lower") {
         std::vector<uint32_t> outs;
         s.change_case(a, base == "to_lower", outs);

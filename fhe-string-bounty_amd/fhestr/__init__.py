@@ -118,8 +118,8 @@ EXPORTS = [
     "fhe_str_trim_start", "fhe_str_trim_end", "fhe_str_strip", "fhe_str_replace", "fhe_str_replace_clear",
     "fhe_plan_lut_count", "fhe_plan_export_lut", "fhe_engine_set_stream", "fhe_engine_reset_stream",
     "fhe_str_len", "fhe_str_is_empty", "fhe_str_strip_prefix_clear", "fhe_str_strip_suffix_clear",
-] + [f"fhe_str_{n}{s}" for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find", "rfind", "eq_ignore_case", "lt", "le", "gt", "ge")
-     for s in ("", "_clear")]
+] + [f"fhe_str_{n}{s}" for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find", "rfind", "eq_ignore_case", "lt", "le", "gt", "ge", "concat")
+     for s in ("", "_clear")] + ["fhe_str_repeat_clear"]
 
 
 def lib() -> C.CDLL:
@@ -202,7 +202,8 @@ def lib() -> C.CDLL:
     sig("fhe_str_is_empty", vp, vp, u32, vp)
     sig("fhe_str_strip_prefix_clear", vp, vp, u32, vp, u32, vp)
     sig("fhe_str_strip_suffix_clear", vp, vp, u32, vp, u32, vp)
-    for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find", "rfind", "eq_ignore_case", "lt", "le", "gt", "ge"):
+    sig("fhe_str_repeat_clear", vp, vp, u32, u32, vp)
+    for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find", "rfind", "eq_ignore_case", "lt", "le", "gt", "ge", "concat"):
         sig(f"fhe_str_{n}", vp, vp, u32, vp, u32, vp)
         sig(f"fhe_str_{n}_clear", vp, vp, u32, vp, u32, vp)
     for n in ("trim_start", "trim_end", "strip"):
@@ -690,6 +691,25 @@ class FheStringOps:
                 raise FheError("replace: `from` and `to` must have the same capacity")
             both = np.concatenate([frm, to])
             _check(lib().fhe_str_replace(self.engine.handle, _ptr(a), a_cap, _ptr(both), f_cap, _ptr(out)))
+        return out
+
+    def concat(self, a, b):
+        """a ++ b (padding of a removed); b encrypted (any capacity) or clear bytes."""
+        a, a_cap = self._cap(a)
+        if isinstance(b, (bytes, bytearray)):
+            out = np.zeros(((a_cap + len(b)) * self.bpc, self.engine.params.big_size), dtype=np.uint64)
+            buf = (C.c_uint8 * max(1, len(b)))(*b)
+            _check(lib().fhe_str_concat_clear(self.engine.handle, _ptr(a), a_cap, buf, len(b), _ptr(out)))
+        else:
+            b, b_cap = self._cap(b)
+            out = np.zeros(((a_cap + b_cap) * self.bpc, self.engine.params.big_size), dtype=np.uint64)
+            _check(lib().fhe_str_concat(self.engine.handle, _ptr(a), a_cap, _ptr(b), b_cap, _ptr(out)))
+        return out
+
+    def repeat(self, a, count: int):
+        a, a_cap = self._cap(a)
+        out = np.zeros((count * a_cap * self.bpc, self.engine.params.big_size), dtype=np.uint64)
+        _check(lib().fhe_str_repeat_clear(self.engine.handle, _ptr(a), a_cap, count, _ptr(out)))
         return out
 
     def to_upper(self, a): return self._unary("to_upper", a)

@@ -167,7 +167,8 @@ int fhe_plan_gather_outputs_dev(fhe_plan *plan, const uint64_t *d_pool, uint64_t
  * blocks, little endian (integer/block_decomposition.rs:119-144): cap * blocks * (kN+1) u64.
  * Results decrypt to what the clear-text function gives on the unpadded ASCII strings.
  * op in {"eq","ne","starts_with","ends_with","contains","find"} (+ "_clear" suffix for a clear
- * pattern) or {"to_upper","to_lower","trim_start","trim_end","strip","replace","replace_clear"}.  Outputs: one 0/1 block; find: found block then
+ * pattern) or {"to_upper","to_lower","trim_start","trim_end","strip","replace","replace_clear","concat",
+ * "concat_clear","repeat_clear"}.  Outputs: one 0/1 block; find: found block then
  * ceil(log_msg_mod(cap+1)) index digits (little endian); case ops: the whole string. */
 int fhe_str_plan_create(fhe_engine *eng, const char *op, uint32_t a_cap, uint32_t b_cap,
                         const uint8_t *clear, uint32_t clear_len, uint32_t world, fhe_plan **out);
@@ -191,6 +192,12 @@ FHE_STR_BINARY_DECL(lt)               /* lexicographic (byte-wise) order, like R
 FHE_STR_BINARY_DECL(le)
 FHE_STR_BINARY_DECL(gt)
 FHE_STR_BINARY_DECL(ge)
+/* concat: a followed by b (a's padding removed); out = (a_cap + b_cap) * blocks LWEs, resp. a_cap + pat_len
+ * for the clear form.  Plan op names "concat" / "concat_clear". */
+FHE_STR_BINARY_DECL(concat)
+/* repeat: a repeated `count` (clear, 1..255) times; out = count * a_cap * blocks LWEs.  Plan op name
+ * "repeat_clear" with the count as the one clear byte. */
+int fhe_str_repeat_clear(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint32_t count, uint64_t *out);
 /* whitespace = ASCII 9..13 and 32; results are re-padded with zeros (whole string returned) */
 int fhe_str_trim_start(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
 int fhe_str_trim_end(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);

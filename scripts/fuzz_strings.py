@@ -55,7 +55,7 @@ for case in range(N_CASES):
     ea, eb = enc(a, cap), enc(b, b_cap)
     op = str(rng.choice(["eq", "ne", "lt", "le", "gt", "ge", "eqic", "starts", "ends", "contains", "find", "rfind",
                          "upper", "lower", "trim_start", "trim_end", "strip", "replace", "len", "is_empty",
-                         "strip_prefix", "strip_suffix"]))
+                         "strip_prefix", "strip_suffix", "concat", "repeat"]))
     clear = bool(rng.random() < 0.5)
     rhs = b if clear else eb
     ctx = (op, a, b, cap, b_cap, clear)
@@ -103,6 +103,11 @@ for case in range(N_CASES):
         check(op, digits_to_int(dec(ops.len(ea))), len(a), ctx)
     elif op == "is_empty":
         check(op, int(dec(ops.is_empty(ea))[0]), int(len(a) == 0), ctx)
+    elif op == "concat":
+        check(op, dec_str(ops.concat(ea, rhs)), a + b, ctx)
+    elif op == "repeat":
+        n = int(rng.integers(1, 4))
+        check(op, dec_str(ops.repeat(ea, n)), a * n, ctx + (n,))
     elif op in ("strip_prefix", "strip_suffix"):
         bit, out = getattr(ops, op)(ea, b)
         had = a.startswith(b) if op == "strip_prefix" else a.endswith(b)

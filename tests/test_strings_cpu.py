@@ -230,3 +230,17 @@ def test_random_circuits_offline_plan_vs_clear_semantics(toy_k1, seed):
     values = [int(v) for v in rng.integers(0, 4, size=6)]
     out = run_with_oracle(plan, toy_k1.ck.encrypt_many(values), toy_k1.sk)
     assert toy_k1.ck.decrypt_many(out).tolist() == evaluate(values)
+
+
+@pytest.mark.parametrize("a,b", [(b"hello", b"wd"), (b"", b"abc"), (b"abc", b""), (b"", b""), (b"abcdefgh", b"ijkl"),
+                                 (b"a", b"b"), (b"ab cd", b" ef")])
+def test_concat_repeat_offline_plan_vs_python(toy_k1, a, b):
+    """concat removes a's padding; repeat is iterated concat (Rust's `+` and str::repeat)."""
+    import fhestr
+    P = to_fhestr_params(O.TOY_K1)
+    assert fhestr.blocks_to_string(P, _run(toy_k1, "concat", a, b)) == a + b                    # out cap 8 + 4
+    assert fhestr.blocks_to_string(P, _run(toy_k1, "concat", a, ("clear", b))) == a + b
+    if len(a) <= 4:
+        plan = _plan("repeat_clear", 4, 0, bytes([3]))
+        got = toy_k1.ck.decrypt_many(run_with_oracle(plan, _enc(toy_k1, a, 4), toy_k1.sk))
+        assert fhestr.blocks_to_string(P, got) == a * 3
