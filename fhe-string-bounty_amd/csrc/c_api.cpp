@@ -21,6 +21,7 @@ using fhe::fail;
 extern "C" {
 
 const char* fhe_last_error(void) { return fhe::g_last_error.c_str(); }
+const char* fhe_kernel_revision(void) { return FHESTR_KERNEL_REVISION; }
 
 int fhe_engine_create(const fhe_params_t* params, int device, fhe_engine** out) {
     API_BEGIN
@@ -187,6 +188,7 @@ namespace fhe {
 int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t b_cap,
                     const uint8_t* clear, uint32_t clear_len);
 }
+#include "noise_model.h"
 
 struct fhe_plan {
     fhe::Circuit* c;
@@ -267,6 +269,7 @@ int fhe_plan_lin(fhe_plan* p, const uint32_t* nodes, const int32_t* coeffs, uint
                  int64_t constant, uint32_t* node) {
     API_BEGIN
     PLAN_BUILDING(p); CHECK_PTR(node);
+    if (n_terms) { CHECK_PTR(nodes); CHECK_PTR(coeffs); }
     std::vector<fhe::Term> terms;
     for (uint32_t i = 0; i < n_terms; i++) terms.push_back({nodes[i], coeffs[i]});
     *node = p->c->lin(terms, constant);
@@ -280,6 +283,23 @@ int fhe_plan_pbs(fhe_plan* p, uint32_t src, uint32_t lut, uint32_t* node) {
     PLAN_BUILDING(p); CHECK_PTR(node);
     *node = p->c->pbs(src, lut);
     if (p->c->failed()) return fail(p->c->take_error());
+    return 0;
+    API_END
+}
+
+int fhe_plan_pbs_signed(fhe_plan* p, uint32_t src, uint32_t lut, uint32_t* node) {
+    API_BEGIN
+    PLAN_BUILDING(p); CHECK_PTR(node);
+    *node = p->c->pbs(src, lut, true);
+    if (p->c->failed()) return fail(p->c->take_error());
+    return 0;
+    API_END
+}
+
+int fhe_plan_set_owner_hint(fhe_plan* p, int rank) {
+    API_BEGIN
+    PLAN_BUILDING(p);
+    p->c->set_owner_hint(rank);
     return 0;
     API_END
 }
@@ -304,6 +324,7 @@ int fhe_plan_finalize(fhe_plan* p, uint32_t world) {
 static int str_plan(const fhe_params_t& params, fhe::Engine* eng, const char* op, uint32_t a_cap,
                     uint32_t b_cap, const uint8_t* clear, uint32_t clear_len, uint32_t world, fhe_plan** out) {
     fhe::Circuit* c = new fhe::Circuit(params, eng);
+    c->set_build_world(world);
     if (fhe::build_string_op(*c, op, a_cap, b_cap, clear, clear_len) || c->finalize(world)) {
         delete c;
         return 1;
@@ -365,13 +386,55 @@ static const fhe::Circuit::Level* plan_level(const fhe_plan* p, uint32_t level) 
     return nullptr;
 }
 
-int fhe_plan_level_info(const fhe_plan* p, uint32_t level, uint32_t info[4]) {
+int fhe_plan_level_info(const fhe_plan* p, uint32_t level, uint32_t info[8]) {
     API_BEGIN
     PLAN_READY(p); CHECK_PTR(info);
     const auto* lv = plan_level(p, level);
     if (!lv) return fail("bad level");
-    info[0] = (uint32_t)lv->off.size() - 1; info[1] = lv->base; info[2] = lv->per_rank;
-    info[3] = (uint32_t)lv->src.size();
+    info[0] = (uint32_t)lv->off.size() - 1; info[1] = lv->local_base; info[2] = lv->local_size;
+    info[3] = lv->e_max; info[4] = lv->recv_base; info[5] = (uint32_t)lv->src.size();
+    info[6] = info[7] = 0;
+    return 0;
+    API_END
+}
+
+int fhe_plan_level_rank_info(const fhe_plan* p, uint32_t level, uint32_t rank, uint32_t info[3]) {
+    API_BEGIN
+    PLAN_READY(p); CHECK_PTR(info);
+    if (level >= p->c->n_levels()) return fail("bad level");
+    if (rank >= p->c->world()) return fail("bad rank");
+    const auto& lv = p->c->level(level);
+    info[0] = lv.rank_off[rank]; info[1] = lv.rank_off[rank + 1]; info[2] = lv.n_export[rank];
+    return 0;
+    API_END
+}
+
+int fhe_plan_noise_info(const fhe_plan* p, double info[4]) {
+    API_BEGIN
+    CHECK_PTR(p); CHECK_PTR(info);
+    const fhe::NoiseModel m = fhe::noise_model(p->c->params());
+    info[0] = p->c->max_pbs_input_noise();
+    info[1] = p->c->noise_budget();
+    info[2] = m.log2_pfail(p->c->max_pbs_input_noise());
+    info[3] = (double)p->c->gathered_lwes();
+    return 0;
+    API_END
+}
+
+int fhe_noise_model(const fhe_params_t* params, double out[6]) {
+    API_BEGIN
+    CHECK_PTR(params); CHECK_PTR(out);
+    const fhe::NoiseModel m = fhe::noise_model(*params);
+    out[0] = m.v_pbs; out[1] = m.v_ks; out[2] = m.v_ms; out[3] = m.half_box;
+    out[4] = fhe::default_noise_budget(*params); out[5] = m.log2_pfail(out[4]);
+    return 0;
+    API_END
+}
+
+int fhe_plan_set_noise_budget(fhe_plan* p, double budget) {
+    API_BEGIN
+    PLAN_BUILDING(p);
+    p->c->set_noise_budget(budget);
     return 0;
     API_END
 }
@@ -399,10 +462,10 @@ int fhe_plan_run(fhe_plan* p, const uint64_t* inputs, uint64_t* outputs) {
     API_END
 }
 
-int fhe_plan_run_level_slice_dev(fhe_plan* p, uint64_t* d_pool, uint32_t level, uint32_t lo, uint32_t hi) {
+int fhe_plan_run_level_rank_dev(fhe_plan* p, uint64_t* d_pool, uint32_t level, uint32_t rank) {
     API_BEGIN
     PLAN_READY(p); CHECK_PTR(d_pool);
-    return p->c->run_level_slice(d_pool, level, lo, hi);
+    return p->c->run_level_rank(d_pool, level, rank);
     API_END
 }
 

@@ -2,7 +2,10 @@
 #include "circuit.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
+
+#include "noise_model.h"
 
 namespace fhe {
 
@@ -13,11 +16,17 @@ namespace fhe {
             return fail(std::string(#expr) + ": " + hipGetErrorString(_e));                   \
     } while (0)
 
+Circuit::Circuit(const fhe_params_t& params, Engine* eng) : p_(params), eng_(eng) {
+    noise_budget_ = default_noise_budget(params);
+}
+
 uint32_t Circuit::input(uint64_t degree) {
     Node n;
     n.kind = Node::INPUT;
     n.level = 0;
-    n.degree = degree;
+    n.vmin = 0;
+    n.vmax = (int64_t)degree;
+    n.noise = 1.0;             // a fresh ciphertext counts as nominal (shortint/ciphertext/mod.rs:13-26)
     n.slot = n_inputs_++;
     nodes_.push_back(n);
     return (uint32_t)nodes_.size() - 1;
@@ -36,28 +45,49 @@ void Circuit::flatten(uint32_t id, int64_t mult, std::map<uint32_t, int64_t>& ac
 uint32_t Circuit::lin(const std::vector<Term>& terms, int64_t cst, int64_t degree_override) {
     std::map<uint32_t, int64_t> acc;
     int64_t c = cst;
-    // degree bound from the operands as given (an operand LIN may carry a tighter, caller-asserted
-    // bound than its flattened leaves would suggest)
-    int64_t maxv = cst > 0 ? cst : 0;
+    // value range from the operands as given (an operand LIN may carry a tighter, caller-asserted
+    // range than its flattened leaves would suggest)
+    int64_t lo = cst, hi = cst;
     for (const Term& t : terms) {
         if (t.node >= nodes_.size()) { error_ = "lin: bad node id"; return 0; }
-        if (t.coeff > 0) maxv += (int64_t)t.coeff * (int64_t)nodes_[t.node].degree;
+        const Node& s = nodes_[t.node];
+        if (t.coeff >= 0) { lo += (int64_t)t.coeff * s.vmin; hi += (int64_t)t.coeff * s.vmax; }
+        else              { lo += (int64_t)t.coeff * s.vmax; hi += (int64_t)t.coeff * s.vmin; }
         flatten(t.node, t.coeff, acc, c);
     }
     Node n;
     n.kind = Node::LIN;
     n.cst = c;
     uint32_t lvl = 0;
+    double noise = 0.0;
     for (auto& kv : acc) {
         if (kv.second == 0) continue;
         if (kv.second > INT32_MAX || kv.second < INT32_MIN) { error_ = "lin: coefficient overflow"; return 0; }
         n.terms.push_back({kv.first, (int32_t)kv.second});
         lvl = std::max(lvl, nodes_[kv.first].level);
+        noise += (double)kv.second * (double)kv.second * nodes_[kv.first].noise;   // add.rs:523, on variances
     }
     n.level = lvl;
-    n.degree = degree_override >= 0 ? (uint64_t)degree_override : (uint64_t)maxv;
+    n.noise = noise;
+    if (degree_override >= 0) { n.vmin = 0; n.vmax = degree_override; }
+    else { n.vmin = lo; n.vmax = hi; }
     nodes_.push_back(n);
     return (uint32_t)nodes_.size() - 1;
+}
+
+int Circuit::owner_of(uint32_t id) const {
+    const Node& n = nodes_[id];
+    if (n.kind == Node::PBS) return n.owner;
+    if (n.kind == Node::INPUT) return -1;
+    int owner = -1;
+    for (const Term& t : n.terms) {
+        const Node& s = nodes_[t.node];
+        if (s.kind != Node::PBS) continue;            // inputs are replicated on every rank
+        if (s.owner < 0) return -1;
+        if (owner >= 0 && owner != s.owner) return -1;
+        owner = s.owner;
+    }
+    return owner;
 }
 
 uint32_t Circuit::lut(const std::vector<uint64_t>& table) {
@@ -73,29 +103,51 @@ uint32_t Circuit::lut(const std::vector<uint64_t>& table) {
     return id;
 }
 
-uint32_t Circuit::pbs(uint32_t id, uint32_t lut_id) {
+uint32_t Circuit::pbs(uint32_t id, uint32_t lut_id, bool signed_input) {
     if (id >= nodes_.size()) { error_ = "pbs: bad node id"; return 0; }
     if (lut_id >= lut_tables_.size()) { error_ = "pbs: LUT was not created through this plan"; return 0; }
     const std::vector<uint64_t>* table = &lut_tables_[lut_id];
     uint32_t src = id;
     if (nodes_[id].kind != Node::LIN) src = lin({{id, 1}});
     const Node& s = nodes_[src];
-    if (s.degree >= total_modulus()) {
-        error_ = "pbs: input degree " + std::to_string(s.degree) + " overflows the message+carry space";
+    const int64_t T = (int64_t)total_modulus();
+    if (s.vmax >= T) {
+        error_ = "pbs: input degree " + std::to_string(s.vmax) + " overflows the message+carry space";
+        return 0;
+    }
+    if (s.vmin < 0 && !signed_input) {
+        error_ = "pbs: input may be negative (down to " + std::to_string(s.vmin) + "): it would wrap into the padding bit "
+                 "and be read through the table's negacyclic extension; add a constant, or declare a signed input";
+        return 0;
+    }
+    if (s.vmin <= -T) {
+        error_ = "pbs: signed input " + std::to_string(s.vmin) + " leaves the padding bit's range";
         return 0;
     }
     if (s.terms.empty()) {
         // trivial ciphertext: clear table lookup (shortint/server_key/mod.rs:763-781)
         const int64_t v = s.cst;
-        if (v < 0 || v >= (int64_t)total_modulus()) { error_ = "pbs: trivial value out of range"; return 0; }
+        if (v < 0 || v >= T) { error_ = "pbs: trivial value out of range"; return 0; }
         return trivial((int64_t)(*table)[(size_t)v]);
+    }
+    // MaxNoiseLevel::validate (shortint/ciphertext/mod.rs:28-55), on variances
+    max_pbs_input_noise_ = std::max(max_pbs_input_noise_, s.noise);
+    if (noise_budget_ > 0.0 && s.noise > noise_budget_) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "pbs: input noise %.1f nominal variances exceeds this parameter set's budget of %.1f",
+                 s.noise, noise_budget_);
+        error_ = buf;
+        return 0;
     }
     Node n;
     n.kind = Node::PBS;
     n.src = src;
     n.lut = lut_id;
     n.level = s.level + 1;
-    n.degree = *std::max_element(table->begin(), table->end());   // mod.rs:855
+    n.vmin = 0;
+    n.vmax = (int64_t)*std::max_element(table->begin(), table->end());   // mod.rs:855
+    n.noise = 1.0;                                                        // NoiseLevel::NOMINAL, mod.rs:856
+    n.owner = (int16_t)(owner_hint_ >= 0 ? owner_hint_ : owner_of(src));
     nodes_.push_back(n);
     n_pbs_++;
     return (uint32_t)nodes_.size() - 1;
@@ -122,9 +174,17 @@ void Circuit::build_csr(Level& lv, const std::vector<uint32_t>& lin_nodes) {
     }
 }
 
+uint64_t Circuit::gathered_lwes() const {
+    uint64_t g = 0;
+    for (const auto& lv : levels_) g += (uint64_t)lv.e_max * world_;
+    return g;
+}
+
 int Circuit::finalize(uint32_t world) {
     if (failed()) return fail("circuit build error: " + error_);
     if (world == 0) return fail("world must be >= 1");
+    if (build_world_ != 1 && build_world_ != world)
+        return fail("plan was built with owner hints for world " + std::to_string(build_world_));
     world_ = world;
     uint32_t max_level = 0;
     for (const Node& n : nodes_)
@@ -132,16 +192,74 @@ int Circuit::finalize(uint32_t world) {
     levels_.assign(max_level, Level());
     for (uint32_t id = 0; id < nodes_.size(); id++)
         if (nodes_[id].kind == Node::PBS) levels_[nodes_[id].level - 1].jobs.push_back(id);
+
+    // ---- owners: hinted / inherited ones stand; the rest of a level inherit from their sources now
+    //      that those are decided (majority, lowest rank on ties), and nodes fed by inputs only are
+    //      dealt out in contiguous slices ----
+    for (auto& lv : levels_) {
+        std::vector<uint32_t> free_nodes;
+        for (uint32_t id : lv.jobs) {
+            Node& n = nodes_[id];
+            if (n.owner >= (int)world) return fail("owner hint beyond the world size");
+            if (world == 1) { n.owner = 0; continue; }
+            if (n.owner >= 0) continue;
+            std::vector<uint32_t> votes(world, 0);
+            uint32_t voters = 0;
+            for (const Term& t : nodes_[n.src].terms)
+                if (nodes_[t.node].kind == Node::PBS) { votes[nodes_[t.node].owner]++; voters++; }
+            if (!voters) { free_nodes.push_back(id); continue; }
+            n.owner = (int16_t)(std::max_element(votes.begin(), votes.end()) - votes.begin());
+        }
+        const uint32_t chunk = ((uint32_t)free_nodes.size() + world - 1) / world;
+        for (uint32_t i = 0; i < free_nodes.size(); i++) nodes_[free_nodes[i]].owner = (int16_t)(i / chunk);
+    }
+    // ---- exports: what another rank, or the output gather, reads ----
+    for (Node& n : nodes_) n.exported = false;
+    if (world > 1) {
+        for (const Node& n : nodes_) {
+            if (n.kind != Node::PBS) continue;
+            for (const Term& t : nodes_[n.src].terms) {
+                Node& s = nodes_[t.node];
+                if (s.kind == Node::PBS && s.owner != n.owner) s.exported = true;
+            }
+        }
+        for (uint32_t o : outputs_) {
+            if (nodes_[o].kind == Node::PBS) nodes_[o].exported = true;
+            if (nodes_[o].kind == Node::LIN)
+                for (const Term& t : nodes_[o].terms)
+                    if (nodes_[t.node].kind == Node::PBS) nodes_[t.node].exported = true;
+        }
+    }
+    // ---- pool layout ----
     uint32_t base = n_inputs_;
     for (auto& lv : levels_) {
-        const uint32_t J = (uint32_t)lv.jobs.size();
-        lv.per_rank = (J + world - 1) / world;
-        lv.base = base;
-        for (uint32_t j = 0; j < J; j++) {
-            nodes_[lv.jobs[j]].slot = base + j;
-            nodes_[lv.jobs[j]].job = j;
+        std::stable_sort(lv.jobs.begin(), lv.jobs.end(), [&](uint32_t a, uint32_t b) {
+            const Node &x = nodes_[a], &y = nodes_[b];
+            if (x.owner != y.owner) return x.owner < y.owner;
+            return x.exported && !y.exported;
+        });
+        lv.rank_off.assign(world + 1, 0);
+        lv.n_export.assign(world, 0);
+        for (uint32_t id : lv.jobs) {
+            lv.rank_off[nodes_[id].owner + 1]++;
+            if (nodes_[id].exported) lv.n_export[nodes_[id].owner]++;
         }
-        base += lv.per_rank * world;
+        lv.local_size = 0;
+        for (uint32_t r = 0; r < world; r++) {
+            lv.local_size = std::max(lv.local_size, lv.rank_off[r + 1]);
+            lv.rank_off[r + 1] += lv.rank_off[r];
+        }
+        lv.e_max = *std::max_element(lv.n_export.begin(), lv.n_export.end());
+        lv.local_base = base;
+        base += lv.local_size;
+        lv.recv_base = base;
+        base += lv.e_max * world;
+        for (uint32_t j = 0; j < lv.jobs.size(); j++) {
+            Node& n = nodes_[lv.jobs[j]];
+            const uint32_t i = j - lv.rank_off[n.owner];      // index inside its rank's range
+            n.job = j;
+            n.slot = n.exported ? lv.recv_base + (uint32_t)n.owner * lv.e_max + i : lv.local_base + i;
+        }
     }
     pool_slots_ = base;
     for (auto& lv : levels_) {
@@ -192,7 +310,7 @@ int Circuit::upload_meta() {
     HIP_TRY(hipMemcpyAsync(d_meta_, host.data(), total, hipMemcpyHostToDevice, eng_->stream));
     HIP_TRY(hipStreamSynchronize(eng_->stream));
     size_t max_jobs = 1;
-    for (auto& lv : levels_) max_jobs = std::max(max_jobs, (size_t)lv.per_rank);
+    for (auto& lv : levels_) max_jobs = std::max(max_jobs, (size_t)lv.local_size);
     const size_t big = (size_t)p_.k * p_.N + 1;
     if (stage_cap_ < max_jobs * big * 8) {
         if (d_stage_) HIP_TRY(hipFree(d_stage_));
@@ -203,21 +321,16 @@ int Circuit::upload_meta() {
     return 0;
 }
 
-int Circuit::run_level_slice(uint64_t* d_pool, uint32_t l, uint32_t lo, uint32_t hi) {
+int Circuit::run_level_rank(uint64_t* d_pool, uint32_t l, uint32_t rank) {
     if (!eng_) return fail("offline plan: no engine bound (there is no CPU execution path)");
     if (l >= levels_.size()) return fail("bad level");
+    if (rank >= world_) return fail("bad rank");
     const Level& lv = levels_[l];
-    hi = std::min<uint32_t>(hi, (uint32_t)lv.jobs.size());
+    const uint32_t lo = lv.rank_off[rank], hi = lv.rank_off[rank + 1];
     if (lo >= hi) return 0;
-    if (hi - lo > lv.per_rank && world_ > 1) return fail("slice larger than the per-rank region");
     if (eng_->use()) return 1;
     const size_t big = (size_t)p_.k * p_.N + 1;
-    if ((size_t)(hi - lo) * big * 8 > stage_cap_) {
-        if (d_stage_) HIP_TRY(hipFree(d_stage_));
-        d_stage_ = nullptr;
-        HIP_TRY(hipMalloc((void**)&d_stage_, (size_t)(hi - lo) * big * 8));
-        stage_cap_ = (size_t)(hi - lo) * big * 8;
-    }
+    if ((size_t)(hi - lo) * big * 8 > stage_cap_) return fail("internal: stage buffer smaller than a level slice");
     const unsigned char* m = reinterpret_cast<const unsigned char*>(d_meta_);
     const uint32_t* d_off = reinterpret_cast<const uint32_t*>(m + lv.meta_off) + lo;
     const uint32_t* d_src = reinterpret_cast<const uint32_t*>(m + lv.meta_src);
@@ -225,7 +338,7 @@ int Circuit::run_level_slice(uint64_t* d_pool, uint32_t l, uint32_t lo, uint32_t
     const uint64_t* d_cst = reinterpret_cast<const uint64_t*>(m + lv.meta_cst) + lo;
     const uint32_t* d_lut = reinterpret_cast<const uint32_t*>(m + lv.meta_lut) + lo;
     if (eng_->lincomb_dev(d_pool, d_off, d_src, d_coeff, d_cst, d_stage_, hi - lo)) return 1;
-    return eng_->ks_pbs_dev(d_stage_, d_lut, d_pool + (size_t)(lv.base + lo) * big, hi - lo);
+    return eng_->ks_pbs_dev(d_stage_, d_lut, d_pool + (size_t)lv.local_base * big, hi - lo);
 }
 
 int Circuit::gather_outputs(const uint64_t* d_pool, uint64_t* d_out) {
@@ -263,7 +376,7 @@ int Circuit::run_host_parts(const uint64_t* const* parts, const uint32_t* counts
     }
     if (placed != n_inputs_) return fail("run_host: fewer input LWEs than the plan has inputs");
     for (uint32_t l = 0; l < levels_.size(); l++)
-        if (run_level_slice(d_own_pool_, l, 0, (uint32_t)levels_[l].jobs.size())) return 1;
+        if (run_level_rank(d_own_pool_, l, 0)) return 1;
     if (gather_outputs(d_own_pool_, d_own_out_)) return 1;
     HIP_TRY(hipMemcpyAsync(outputs, d_own_out_, (size_t)n_outputs() * big * 8, hipMemcpyDeviceToHost, eng_->stream));
     HIP_TRY(hipStreamSynchronize(eng_->stream));

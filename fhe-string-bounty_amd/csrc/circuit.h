@@ -13,9 +13,22 @@
 // keyswitch launch + one blind-rotate launch over all ciphertexts of that level.  LIN nodes are
 // never materialised on their own; they are folded into the gather of the PBS that consumes them.
 //
-// Metadata follows the reference's bookkeeping (shortint/ciphertext/mod.rs:263-270,
-// server_key/mod.rs:855-856): `degree` = largest clear value a node can hold, checked against
-// msg_mod*carry_mod-1 before every PBS so a packing overflow is a build-time error.
+// Metadata follows the reference's bookkeeping (shortint/ciphertext/mod.rs:28-55,263-270,
+// server_key/mod.rs:855-856, add.rs:520-524):
+//   value range [vmin, vmax] -- `degree` made two-sided: a PBS input must lie in [0, msg*carry) (or in
+//       (-msg*carry, msg*carry) when the caller declares that it uses the padding bit), otherwise
+//       the build fails instead of silently evaluating the negacyclic extension of the table;
+//   noise -- variance in units of one nominal ciphertext (fresh PBS output = NoiseLevel::NOMINAL):
+//       a linear combination carries sum coeff^2 * noise(source) over its *materialised* sources
+//       (the same source reached twice is merged first), checked before every PBS against the
+//       parameter set's budget (noise_model.h; the reference's MaxNoiseLevel::validate,
+//       shortint/ciphertext/mod.rs:28-55).
+//
+// Multi-GPU: every PBS node has an owner rank; a rank runs its own jobs of a level and
+// only the nodes another rank (or the output gather) consumes are exchanged -- one all-gather of
+// `e_max` ciphertexts per rank for a level that exports anything, no collective otherwise.  Builders
+// steer ownership with owner hints (e.g. one slice of the characters per rank, reduced locally to a
+// single block before anything is communicated).
 #pragma once
 #include <stdint.h>
 
@@ -34,30 +47,37 @@ struct Term {
 
 struct Node {
     enum Kind : uint8_t { INPUT, LIN, PBS } kind;
+    bool exported = false;     // PBS: consumed by another rank or by the outputs -> part of the all-gather
+    int16_t owner = -1;        // PBS: rank that runs it (-1 while building = decided at finalize)
     uint32_t level = 0;        // 0 for inputs; PBS: 1 + max level of deps; LIN: max level of deps
-    uint64_t degree = 0;       // largest clear value (message+carry space)
+    int64_t vmin = 0, vmax = 0;   // clear value range (message+carry space; vmin < 0 = reaches the padding bit)
+    double noise = 0.0;        // variance, in units of one nominal ciphertext
     // LIN (already flattened onto materialised nodes: INPUT / PBS)
     std::vector<Term> terms;
     int64_t cst = 0;           // clear constant (in message units, scaled by delta at execution)
     // PBS
     uint32_t src = 0;          // node id of the LIN/any node fed to the table
-    uint32_t lut = 0;          // engine LUT id
+    uint32_t lut = 0;          // plan-local LUT id
     // materialised nodes
-    uint32_t slot = 0;         // pool slot
+    uint32_t slot = 0;         // pool slot consumers read
     uint32_t job = 0;          // index inside its level
+    uint64_t degree() const { return vmax > 0 ? (uint64_t)vmax : 0; }
 };
 
 class Circuit {
 public:
     // eng may be null: the plan can then be built, finalised and exported, but not run
-    Circuit(const fhe_params_t& params, Engine* eng) : p_(params), eng_(eng) {}
+    Circuit(const fhe_params_t& params, Engine* eng);
 
     uint32_t input(uint64_t degree);                             // next input ciphertext
-    // degree_override >= 0 replaces the conservative degree bound (caller knows better)
+    // degree_override >= 0: the caller asserts the value lies in [0, degree_override] (it knows more
+    // than interval arithmetic, e.g. "at most one term is non-zero")
     uint32_t lin(const std::vector<Term>& terms, int64_t cst = 0, int64_t degree_override = -1);
     uint32_t add(uint32_t a, uint32_t b) { return lin({{a, 1}, {b, 1}}); }
     uint32_t trivial(int64_t value) { return lin({}, value); }   // create_trivial (mod.rs:684-721)
-    uint32_t pbs(uint32_t node, uint32_t lut);
+    // apply_lookup_table.  signed_input: the value may be negative, i.e. the torus value uses the
+    // padding bit and the table is read through its negacyclic extension f(x - T) = -f(x).
+    uint32_t pbs(uint32_t node, uint32_t lut, bool signed_input = false);
     // generate_lookup_table with a cache keyed on the table contents (mod.rs:383-399)
     uint32_t lut(const std::vector<uint64_t>& table);
     template <class F>
@@ -67,6 +87,23 @@ public:
         return lut(t);
     }
     void output(uint32_t node) { outputs_.push_back(node); }
+
+    // ---- multi-GPU building hints ----
+    // world the plan is being built for (builders that shard by hand read it); finalize() must be
+    // given the same value.  PBS nodes created while a hint is set belong to that rank.
+    void set_build_world(uint32_t world) { build_world_ = world ? world : 1; }
+    uint32_t build_world() const { return build_world_; }
+    void set_owner_hint(int rank) { owner_hint_ = rank; }
+    int owner_hint() const { return owner_hint_; }
+    // owner known at build time (-1: none yet): hinted PBS nodes, and LIN / PBS nodes all of whose
+    // materialised PBS sources share one owner
+    int owner_of(uint32_t node) const;
+
+    // ---- noise budget ----
+    // largest noise (nominal-variance units) a PBS input may carry; <= 0 disables the check
+    void set_noise_budget(double b) { noise_budget_ = b; }
+    double noise_budget() const { return noise_budget_; }
+    double max_pbs_input_noise() const { return max_pbs_input_noise_; }
 
     uint32_t total_modulus() const { return p_.msg_mod * p_.carry_mod; }
     uint32_t msg_modulus() const { return p_.msg_mod; }
@@ -79,18 +116,24 @@ public:
     std::string take_error() { std::string e; e.swap(error_); return e; }   // report once, then keep building
 
     // ---- finalise + query ----
-    int finalize(uint32_t world);                 // assigns levels' pool regions (padded per rank)
+    int finalize(uint32_t world);                 // owners, exports, pool layout, gather descriptions
     uint32_t n_inputs() const { return n_inputs_; }
     uint32_t n_outputs() const { return (uint32_t)outputs_.size(); }
     uint32_t n_levels() const { return (uint32_t)levels_.size(); }
     uint32_t n_pbs() const { return n_pbs_; }
     uint32_t pool_slots() const { return pool_slots_; }
     uint32_t world() const { return world_; }
+    // ciphertexts every rank receives over all levels' all-gathers (world * e_max summed)
+    uint64_t gathered_lwes() const;
     struct Level {
-        std::vector<uint32_t> jobs;     // PBS node ids
-        uint32_t base = 0;              // first pool slot of the level's region
-        uint32_t per_rank = 0;          // padded jobs per rank
-        // CSR gather description of every job (host copy; uploaded at finalize)
+        std::vector<uint32_t> jobs;       // PBS node ids, ordered by (owner, exported first, creation order)
+        std::vector<uint32_t> rank_off;   // [world + 1]: rank r runs jobs [rank_off[r], rank_off[r+1])
+        std::vector<uint32_t> n_export;   // [world]: the first n_export[r] jobs of rank r are exported
+        uint32_t e_max = 0;               // all-gather count per rank; 0 = this level needs no collective
+        uint32_t local_base = 0;          // job i of a rank's range writes pool slot local_base + i ...
+        uint32_t local_size = 0;          // ... (same slots on every rank, each holding its own data)
+        uint32_t recv_base = 0;           // all-gather destination: [world][e_max] slots
+        // CSR gather description of every job, in `jobs` order (host copy; uploaded at finalize)
         std::vector<uint32_t> off, src, lut;
         std::vector<int32_t> coeff;
         std::vector<uint64_t> cst;      // already multiplied by delta
@@ -102,7 +145,7 @@ public:
 
     // ---- execution on the engine's GPU; d_pool holds pool_slots() big LWEs ----
     int upload_meta();
-    int run_level_slice(uint64_t* d_pool, uint32_t level, uint32_t lo, uint32_t hi);
+    int run_level_rank(uint64_t* d_pool, uint32_t level, uint32_t rank);   // that rank's jobs -> its local region
     int gather_outputs(const uint64_t* d_pool, uint64_t* d_out);
     int run_host(const uint64_t* inputs, uint64_t* outputs);
     int run_host_parts(const uint64_t* const* parts, const uint32_t* counts, uint32_t n_parts, uint64_t* outputs);     // single GPU, host buffers
@@ -121,7 +164,9 @@ private:
     std::map<std::vector<uint64_t>, uint32_t> lut_cache_;
     std::vector<Level> levels_;
     Level out_;
-    uint32_t n_inputs_ = 0, n_pbs_ = 0, pool_slots_ = 0, world_ = 1;
+    uint32_t n_inputs_ = 0, n_pbs_ = 0, pool_slots_ = 0, world_ = 1, build_world_ = 1;
+    int owner_hint_ = -1;
+    double noise_budget_ = 0.0, max_pbs_input_noise_ = 0.0;
     std::string error_;
     void* d_meta_ = nullptr;
     uint64_t* d_stage_ = nullptr;   // lincomb output / keyswitch input of one level slice

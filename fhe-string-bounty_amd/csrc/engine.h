@@ -9,6 +9,10 @@
 
 #include "../../include/fhestr.h"
 
+// bumped whenever a device kernel changes; profiles/r02_counters.json records the revision its
+// rocprofv3 counters were taken on and bench.py only attaches them to a matching build
+#define FHESTR_KERNEL_REVISION "r02.1"
+
 namespace fhe {
 
 // GGSWs in the bootstrapping key: n (classic PBS) or n/g * 2^g (multi-bit, grouping factor g)

@@ -105,7 +105,7 @@ public:
     // (Only equality can be read this way: a table that is 1 on both signs cannot be negacyclic.)
     uint32_t packed_pair_eq(uint32_t lo_a, uint32_t hi_a, uint32_t lo_b, uint32_t hi_b) {
         const uint32_t l = c.lut_fn([](uint64_t x) { return (uint64_t)(x == 0); });
-        return c.pbs(c.lin({{lo_a, 1}, {hi_a, (int32_t)M}, {lo_b, -1}, {hi_b, -(int32_t)M}}, 0, (int64_t)T - 1), l);
+        return c.pbs(c.lin({{lo_a, 1}, {hi_a, (int32_t)M}, {lo_b, -1}, {hi_b, -(int32_t)M}}), l, /*signed_input=*/true);
     }
     // equality bits of two encrypted chars: bpc bits (reference shape) or bpc/2 bits (packed)
     void char_eq_bits(const std::vector<uint32_t>& x, const std::vector<uint32_t>& y, std::vector<uint32_t>& out) {
@@ -639,8 +639,8 @@ public:
                 const uint32_t l = c.lut_fn([](uint64_t x) { return (uint64_t)(x != 0); });
                 for (int k = (int)bpc - 2; k >= 0; k -= 2) {
                     const uint32_t d = c.lin({{a.ch[i][k], 1}, {a.ch[i][k + 1], (int32_t)M}, {b->ch[i][k], -1},
-                                              {b->ch[i][k + 1], -(int32_t)M}}, 0, (int64_t)T - 1);
-                    signs.push_back(c.lin({{c.pbs(d, l), 1}}, 1, 2));
+                                              {b->ch[i][k + 1], -(int32_t)M}});
+                    signs.push_back(c.lin({{c.pbs(d, l, /*signed_input=*/true), 1}}, 1, 2));
                 }
                 continue;
             }

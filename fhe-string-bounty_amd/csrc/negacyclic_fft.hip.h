@@ -765,9 +765,25 @@ __device__ __forceinline__ void fft_inverse_multi(cplx (*x)[PL::R], const FftCon
 
 // ---- integer <-> f64 conversions -------------------------------------------------------------
 
-// torus f64 -> u64: reference commons/math/torus/mod.rs:72-78 (from_torus).  rint() (ties-to-even)
-// stands in for Rust's round() (ties away); they differ only for exact .5 inputs, by one ulp of
-// the 2^-64 grid, far below the FFT error the reference tolerates (fft/tests.rs:40-46).
+// torus f64 -> u64: reference commons/math/torus/mod.rs:72-78 (from_torus) =
+// round((x - round(x)) * 2^64) as i64 as u64.
+#ifndef FHESTR_FROM_TORUS_ROUND64
+// Here: the fractional part as fixed point, straight out of the mantissa.  v_fract_f64 is exact
+// (x - floor(x) in [0, 1)); adding 1.0 aligns it to 2^-52, so the 52 mantissa bits of the sum ARE
+// round_to_nearest_even(frac * 2^52) and the torus word is that mantissa << 12 (a sum that rounds
+// up to 2.0 has mantissa 0 = the torus' wrap-around).  [0, 1) instead of the reference's
+// [-1/2, 1/2) is the same element mod 2^64.  Against the reference's rounding on the 2^-64 grid
+// this adds an unbiased error of at most 2^-53 of the torus, 2^-27 of the f64 FFT's own error
+// (the reference tolerates 2^14 ulp, fft/tests.rs:40-46, and measures ~2^38); 2 f64 + 2 integer
+// instructions instead of 9 f64.
+__device__ __forceinline__ uint64_t from_torus(double x) {
+    const double u = __builtin_amdgcn_fract(x) + 1.0;
+    const uint32_t lo = (uint32_t)__double2loint(u), hi = (uint32_t)__double2hiint(u);
+    return ((uint64_t)__builtin_amdgcn_alignbit(hi, lo, 20) << 32) | (uint64_t)(lo << 12);
+}
+#else
+// The reference's formula literally; rint() (ties-to-even) stands in for Rust's round() (ties away):
+// they differ only for exact .5 inputs, by one ulp of the 2^-64 grid.
 __device__ __forceinline__ uint64_t from_torus(double x) {
     double fr = x - rint(x);
     double y = rint(fr * 18446744073709551616.0);
@@ -777,6 +793,7 @@ __device__ __forceinline__ uint64_t from_torus(double x) {
     uint32_t lo = (uint32_t)l;                            // v_cvt_u32_f64
     return ((uint64_t)hi << 32) | lo;
 }
+#endif
 
 // signed i64 -> f64 (exact for |v| < 2^53, otherwise correctly rounded via two-part sum)
 __device__ __forceinline__ double i64_to_f64(uint64_t v) {

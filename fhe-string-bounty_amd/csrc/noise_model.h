@@ -1,0 +1,96 @@
+// noise_model.h -- variance model of one KS -> PBS atomic pattern, used to bound what a plan may feed
+// to a lookup table.
+//
+// The reference guards its operations with `MaxNoiseLevel::validate` (shortint/ciphertext/mod.rs:28-55):
+// a ciphertext's noise level (in units of the nominal, fresh-PBS-output level) must stay below
+// max_noise_level = (msg*carry - 1) / (msg - 1), and levels add under addition (server_key/add.rs:523).
+// That is a norm-1 rule on standard deviations; the quantity that decides correctness is the variance
+// of the phase the blind rotation sees,
+//     V(input) = nu * V_pbs + V_ks + V_ms,        nu = sum_i coeff_i^2 * noise_i   (Circuit::Node::noise)
+// against half a table box, delta/2 (fft_impl/common.rs:26-43 rounds the phase to 2N levels):
+//   V_pbs  variance of a bootstrapped ciphertext: n CMUXes, each adding the GGSW noise seen through the
+//          decomposed accumulator, the decomposition's rounding error against the binary GLWE key, and
+//          the f64 FFT's rounding error (ggsw.rs:477-598; dominant for the 2^23 base of
+//          PARAM_MESSAGE_2_CARRY_2),
+//   V_ks   keyswitch: k N l_ks digits against fresh KSK encryptions + the rounding of the mask
+//          (lwe_keyswitch.rs:143-169),
+//   V_ms   modulus switch of the n+1 words to 2N levels (common.rs:26-43).
+// Formulas are the usual average-case ones for uniform binary keys (Chillotti et al., "Improved
+// programmable bootstrapping with larger precision", 2021; the concrete-optimizer's
+// variance_external_product_glwe / variance_keyswitch).  The FFT term's constant is calibrated against
+// this engine's measured PBS output noise (tests/test_gpu_noise.py, scripts/noise_budget.py); the
+// model is then checked on the GPU against the measured post-keyswitch / post-modulus-switch spreads.
+// Variances are in units of the torus (q = 1).
+#pragma once
+#include <math.h>
+
+#include "../../include/fhestr.h"
+
+namespace fhe {
+
+struct NoiseModel {
+    double v_pbs = 0, v_ks = 0, v_ms = 0, half_box = 0;
+    double v_pbs_ggsw = 0, v_pbs_round = 0, v_pbs_fft = 0;
+    // log2 of P(|phase error| > delta/2) for a PBS input of `nu` nominal variances (two-sided Gaussian tail)
+    double log2_pfail(double nu) const {
+        const double z = half_box / sqrt(nu * v_pbs + v_ks + v_ms);
+        const double p = erfc(z / sqrt(2.0));
+        if (p > 1e-300) return log2(p);
+        return (-(z * z) / 2 - log(z * sqrt(M_PI / 2))) / log(2.0);   // asymptotic tail
+    }
+    // largest nu whose failure probability stays at or below 2^log2_target (0 if even nu = 0 fails)
+    double budget(double log2_target) const {
+        if (log2_pfail(0.0) > log2_target) return 0.0;
+        double lo = 0.0, hi = 1.0;
+        while (log2_pfail(hi) <= log2_target && hi < 1e12) hi *= 2;
+        if (hi >= 1e12) return hi;
+        for (int i = 0; i < 60; i++) {
+            const double mid = 0.5 * (lo + hi);
+            (log2_pfail(mid) <= log2_target ? lo : hi) = mid;
+        }
+        return lo;
+    }
+};
+
+// f64 FFT rounding: per CMUX and output coefficient, relative error 2^-53 per operation on values of
+// magnitude^2 ~ l (k+1) N (B^2/12) (1/12); kFftNoiseConstant lumps the transform depth (three
+// transforms of log2(N/2) passes each) and is fitted to the measured PBS output noise
+// (PARAM_MESSAGE_2_CARRY_2: std 2.35e-5 of the torus = 2^48.6, of which the decomposition rounding
+// term explains 2.12e-5; gpurun_out/noise1.json, tests/test_gpu_noise.py).
+constexpr double kFftNoiseConstant = 6.0;
+
+inline NoiseModel noise_model(const fhe_params_t& p) {
+    NoiseModel m;
+    const double N = p.N, k = p.k, n = p.n, l = p.pbs_level, lk = p.ks_level;
+    const double B = ldexp(1.0, (int)p.pbs_base_log), Bk = ldexp(1.0, (int)p.ks_base_log);
+    const double steps = p.grouping_factor > 1 ? n / p.grouping_factor : n;
+    m.v_pbs_ggsw = steps * l * (k + 1) * N * (B * B + 2) / 12.0 * p.glwe_std * p.glwe_std;
+    m.v_pbs_round = steps * (1.0 + k * N / 2.0) / (24.0 * pow(B, 2 * l)) + steps * k * N / 32.0 * ldexp(1.0, -128);
+    m.v_pbs_fft = steps * kFftNoiseConstant * ldexp(1.0, -106) * l * (k + 1) * N * (B * B / 144.0) * (1.0 + k * N / 2.0);
+    m.v_pbs = m.v_pbs_ggsw + m.v_pbs_round + m.v_pbs_fft;
+    m.v_ks = k * N * lk * (Bk * Bk + 2) / 12.0 * p.lwe_std * p.lwe_std + k * N / 2.0 / (12.0 * pow(Bk, 2 * lk));
+    m.v_ms = (1.0 + n / 2.0) / (12.0 * 4.0 * N * N);
+    m.half_box = 0.25 / (p.msg_mod * p.carry_mod);   // delta / 2 = 2^63 / (msg*carry) / 2 over 2^64
+    return m;
+}
+
+// Budget a plan enforces at every PBS input.  The parameter sets of shortint/parameters/mod.rs are
+// generated for p_fail <= 2^-40 at the reference's worst-case noise (norm2 = max_noise_level,
+// docs/getting_started/security_and_cryptography.md:96); with the measured FFT term some of them sit a
+// little above that by this model, so the budget is the larger of
+//   * the reference's own rule in variance form, nu <= max_noise_level^2 (the norm-1 bound is reached by
+//     one ciphertext scaled by max_noise_level), and
+//   * what the model allows for a failure probability within a factor 2^kPfailSlackLog2 of the
+//     reference-shaped worst case (nu = max_noise_level^2),
+// i.e. a plan may never be meaningfully noisier than what the reference would accept.
+constexpr double kPfailSlackLog2 = 0.5;
+
+inline double default_noise_budget(const fhe_params_t& p) {
+    const double max_level = (double)(p.msg_mod * p.carry_mod - 1) / (double)(p.msg_mod > 1 ? p.msg_mod - 1 : 1);
+    const double ref_nu = max_level * max_level;
+    const NoiseModel m = noise_model(p);
+    const double by_model = m.budget(m.log2_pfail(ref_nu) + kPfailSlackLog2);
+    return by_model > ref_nu ? by_model : ref_nu;
+}
+
+}  // namespace fhe

@@ -14,7 +14,8 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libfhestr.so")
+# FHESTR_LIB: load another build of the same library (kernel A/B experiments, scripts/ab_bench.sh)
+LIB_PATH = os.environ.get("FHESTR_LIB") or os.path.join(os.path.dirname(_HERE), "libfhestr.so")
 
 
 class FheError(RuntimeError):
@@ -104,7 +105,7 @@ PARAM_MESSAGE_1_CARRY_1_KS_PBS = Params(684, 3, 512, 18, 1, 4, 3, 2, 2,
 _lib = None
 
 EXPORTS = [
-    "fhe_last_error", "fhe_engine_create", "fhe_engine_destroy", "fhe_engine_params",
+    "fhe_last_error", "fhe_kernel_revision", "fhe_engine_create", "fhe_engine_destroy", "fhe_engine_params",
     "fhe_engine_load_keys", "fhe_engine_generate_keys", "fhe_engine_stream", "fhe_engine_synchronize", "fhe_engine_set_variant",
     "fhe_lut_generate", "fhe_lut_upload", "fhe_lut_download", "fhe_lut_count",
     "fhe_keyswitch_batch", "fhe_pbs_batch", "fhe_ks_pbs_batch", "fhe_ks_pbs_batch_dev", "fhe_pbs_ks_batch",
@@ -113,7 +114,9 @@ EXPORTS = [
     "fhe_client_encrypt", "fhe_client_decrypt", "fhe_client_gen_server_keys", "fhe_client_secret_keys",
     "fhe_plan_create", "fhe_plan_destroy", "fhe_plan_input", "fhe_plan_lut", "fhe_plan_lin", "fhe_plan_pbs",
     "fhe_plan_output", "fhe_plan_finalize", "fhe_plan_info", "fhe_plan_level_info", "fhe_plan_export_level",
-    "fhe_plan_run", "fhe_plan_run_level_slice_dev", "fhe_plan_gather_outputs_dev", "fhe_str_plan_create",
+    "fhe_plan_run", "fhe_plan_run_level_rank_dev", "fhe_plan_gather_outputs_dev", "fhe_str_plan_create",
+    "fhe_plan_level_rank_info", "fhe_plan_noise_info", "fhe_noise_model", "fhe_plan_set_noise_budget",
+    "fhe_plan_pbs_signed", "fhe_plan_set_owner_hint",
     "fhe_str_to_upper", "fhe_str_to_lower", "fhe_plan_create_offline", "fhe_str_plan_create_offline",
     "fhe_str_trim_start", "fhe_str_trim_end", "fhe_str_strip", "fhe_str_replace", "fhe_str_replace_clear",
     "fhe_plan_lut_count", "fhe_plan_export_lut", "fhe_engine_set_stream", "fhe_engine_reset_stream",
@@ -144,6 +147,8 @@ def lib() -> C.CDLL:
     PP = C.POINTER(_Params)
     L.fhe_last_error.restype = C.c_char_p
     L.fhe_last_error.argtypes = []
+    L.fhe_kernel_revision.restype = C.c_char_p
+    L.fhe_kernel_revision.argtypes = []
     L.fhe_engine_stream.restype = vp
     L.fhe_engine_stream.argtypes = [vp]
 
@@ -195,7 +200,13 @@ def lib() -> C.CDLL:
     sig("fhe_plan_level_info", vp, u32, C.POINTER(u32))
     sig("fhe_plan_export_level", vp, u32, vp, vp, vp, vp, vp)
     sig("fhe_plan_run", vp, vp, vp)
-    sig("fhe_plan_run_level_slice_dev", vp, vp, u32, u32, u32)
+    sig("fhe_plan_run_level_rank_dev", vp, vp, u32, u32)
+    sig("fhe_plan_level_rank_info", vp, u32, u32, C.POINTER(u32))
+    sig("fhe_plan_noise_info", vp, C.POINTER(C.c_double))
+    sig("fhe_noise_model", PP, C.POINTER(C.c_double))
+    sig("fhe_plan_set_noise_budget", vp, C.c_double)
+    sig("fhe_plan_pbs_signed", vp, u32, u32, C.POINTER(u32))
+    sig("fhe_plan_set_owner_hint", vp, i32)
     sig("fhe_plan_gather_outputs_dev", vp, vp, vp)
     sig("fhe_str_plan_create", vp, C.c_char_p, u32, u32, vp, u32, u32, C.POINTER(vp))
     sig("fhe_str_len", vp, vp, u32, vp)
@@ -217,6 +228,17 @@ def lib() -> C.CDLL:
         getattr(L, name).argtypes = [PP]
     _lib = L
     return L
+
+
+def noise_model(params: "Params") -> dict:
+    """Variance model of one KS -> PBS (csrc/noise_model.h): variances with the torus = 1."""
+    a = (C.c_double * 6)()
+    _check(lib().fhe_noise_model(C.byref(params.c()), a))
+    return dict(zip(("v_pbs", "v_ks", "v_ms", "half_box", "budget", "log2_pfail_at_budget"), map(float, a)))
+
+
+def kernel_revision() -> str:
+    return lib().fhe_kernel_revision().decode()
 
 
 def _check(rc: int):
@@ -521,10 +543,18 @@ class Plan:
         _check(lib().fhe_plan_lin(self._h, _ptr(nodes), _ptr(coeffs), len(terms), constant, C.byref(out)))
         return out.value
 
-    def pbs(self, src: int, lut: int) -> int:
+    def pbs(self, src: int, lut: int, signed: bool = False) -> int:
+        """apply_lookup_table; signed=True declares that the input may be negative (padding bit in use)."""
         out = C.c_uint32()
-        _check(lib().fhe_plan_pbs(self._h, src, lut, C.byref(out)))
+        _check((lib().fhe_plan_pbs_signed if signed else lib().fhe_plan_pbs)(self._h, src, lut, C.byref(out)))
         return out.value
+
+    def set_owner_hint(self, rank: int):
+        """PBS nodes created from now on run on `rank` (-1 = automatic); see include/fhestr.h."""
+        _check(lib().fhe_plan_set_owner_hint(self._h, rank))
+
+    def set_noise_budget(self, budget: float):
+        _check(lib().fhe_plan_set_noise_budget(self._h, budget))
 
     def output(self, node: int):
         _check(lib().fhe_plan_output(self._h, node))
@@ -538,10 +568,20 @@ class Plan:
         _check(lib().fhe_plan_info(self._h, a))
         return dict(zip(("n_inputs", "n_outputs", "n_levels", "n_pbs", "pool_slots", "world"), map(int, a)))
 
+    def noise_info(self) -> dict:
+        a = (C.c_double * 4)()
+        _check(lib().fhe_plan_noise_info(self._h, a))
+        return dict(zip(("max_pbs_input_noise", "budget", "log2_pfail_worst", "gathered_lwes"), map(float, a)))
+
     def level_info(self, level: int) -> dict:
-        a = (C.c_uint32 * 4)()
+        a = (C.c_uint32 * 8)()
         _check(lib().fhe_plan_level_info(self._h, level, a))
-        return dict(zip(("jobs", "base", "per_rank", "terms"), map(int, a)))
+        return dict(zip(("jobs", "local_base", "local_size", "e_max", "recv_base", "terms"), map(int, a)))
+
+    def level_rank_info(self, level: int, rank: int) -> dict:
+        a = (C.c_uint32 * 3)()
+        _check(lib().fhe_plan_level_rank_info(self._h, level, rank, a))
+        return dict(zip(("job_lo", "job_hi", "n_export"), map(int, a)))
 
     def export_level(self, level: int) -> dict:
         li = self.level_info(level)
@@ -568,8 +608,8 @@ class Plan:
         _check(lib().fhe_plan_run(self._h, _ptr(inputs) if inputs.size else None, _ptr(out)))
         return out
 
-    def run_level_slice_dev(self, d_pool: int, level: int, lo: int, hi: int):
-        _check(lib().fhe_plan_run_level_slice_dev(self._h, C.c_void_p(d_pool), level, lo, hi))
+    def run_level_rank_dev(self, d_pool: int, level: int, rank: int):
+        _check(lib().fhe_plan_run_level_rank_dev(self._h, C.c_void_p(d_pool), level, rank))
 
     def gather_outputs_dev(self, d_pool: int, d_out: int):
         _check(lib().fhe_plan_gather_outputs_dev(self._h, C.c_void_p(d_pool), C.c_void_p(d_out)))

@@ -1,21 +1,18 @@
-"""Multi-GPU execution of a plan: one process per GPU, keys replicated, every level's batch of
-KS+PBS jobs split into contiguous per-rank slices, one all-gather of the level's outputs per level
-(RCCL over xGMI through torch.distributed's "nccl" backend).
+"""Multi-GPU execution of a plan: one process per GPU, keys replicated.  Every KS+PBS of a plan has an
+owner rank (csrc/circuit.h): a rank runs its own jobs of a level into its local pool region, and only
+what another rank -- or the final output gather -- consumes is exchanged: one all-gather of `e_max`
+ciphertexts per rank for a level that exports anything (RCCL over xGMI through torch.distributed's
+"nccl" backend), no collective at all for a level that does not.  For FheString::eq on 256 chars over 8
+GPUs that is two all-gathers of one ciphertext per rank (reduce locally, gather the
+reduced blocks).
 
-The reference has no distributed code; the shardable unit is the independent
-KS+PBS of one ciphertext.  The control flow below is backend-agnostic: the
-product backend (GpuBackend) launches HIP kernels through the C ABI; tests may inject a checker
-backend (CPU oracle + gloo) to exercise the sharding protocol without a GPU.
+The reference has no distributed code.  The control flow below is backend-agnostic: the
+product backend (GpuBackend) launches HIP kernels through the C ABI; tests may inject a checker backend
+(CPU oracle + gloo) to exercise the sharding protocol without a GPU.
 """
 from __future__ import annotations
 
 import numpy as np
-
-
-def slice_bounds(jobs: int, per_rank: int, rank: int) -> tuple[int, int]:
-    """Contiguous slice [lo, hi) of a level's jobs owned by `rank` (may be empty)."""
-    lo = min(jobs, rank * per_rank)
-    return lo, min(jobs, lo + per_rank)
 
 
 class ShardedPlanRunner:
@@ -25,17 +22,19 @@ class ShardedPlanRunner:
             raise ValueError(f"plan was finalised for world={info['world']}, runner has world={world}")
         self.plan, self.rank, self.world, self.backend, self.info = plan, rank, world, backend, info
         self.levels = [plan.level_info(l) for l in range(info["n_levels"])]
+        # ciphertexts this rank receives over the whole plan, and the bytes that is
+        self.gathered_lwes = sum(lv["e_max"] * world for lv in self.levels) if world > 1 else 0
+        self.gathered_bytes = self.gathered_lwes * plan.params.big_size * 8
+        self.collectives = sum(1 for lv in self.levels if lv["e_max"]) if world > 1 else 0
 
     def run(self, inputs):
         b = self.backend
         pool = b.alloc_pool(self.info["pool_slots"])
         b.load_inputs(pool, inputs, self.info["n_inputs"])
         for l, lv in enumerate(self.levels):
-            lo, hi = slice_bounds(lv["jobs"], lv["per_rank"], self.rank)
-            if lo < hi:
-                b.run_level_slice(pool, l, lo, hi)
-            if self.world > 1:
-                b.all_gather(pool, lv["base"], lv["per_rank"], self.rank, self.world)
+            b.run_level(pool, l, self.rank)
+            if self.world > 1 and lv["e_max"]:
+                b.all_gather(pool, lv["local_base"], lv["e_max"], lv["recv_base"], self.world)
         return b.gather_outputs(pool, self.info["n_outputs"])
 
 
@@ -62,14 +61,13 @@ class GpuBackend:
         arr = np.ascontiguousarray(inputs, dtype=np.uint64).reshape(n_inputs, self.big)
         pool[:n_inputs].copy_(self.torch.from_numpy(arr.view(np.int64)))
 
-    def run_level_slice(self, pool, level, lo, hi):
-        self.plan.run_level_slice_dev(pool.data_ptr(), level, lo, hi)
+    def run_level(self, pool, level, rank):
+        self.plan.run_level_rank_dev(pool.data_ptr(), level, rank)
 
-    def all_gather(self, pool, base, per_rank, rank, world):
+    def all_gather(self, pool, local_base, e_max, recv_base, world):
         import torch.distributed as dist
-        region = pool[base: base + per_rank * world]
-        own = region[rank * per_rank: (rank + 1) * per_rank].clone()
-        dist.all_gather_into_tensor(region, own, group=self.group)
+        dist.all_gather_into_tensor(pool[recv_base: recv_base + e_max * world],
+                                    pool[local_base: local_base + e_max], group=self.group)
 
     def gather_outputs(self, pool, n_outputs):
         out = self.torch.empty((n_outputs, self.big), dtype=self.torch.int64, device=self.device)

@@ -49,6 +49,8 @@ typedef struct fhe_engine fhe_engine;
 
 /* Last error message of the calling thread ("" if none). */
 const char *fhe_last_error(void);
+/* Revision tag of the device kernels in this build (profiles/ counter files are keyed on it). */
+const char *fhe_kernel_revision(void);
 
 /* ---- engine + keys ------------------------------------------------------------------------ */
 /* replaces ServerKey construction (shortint/engine/server_side.rs:54-160), evaluation side only */
@@ -129,7 +131,8 @@ int fhe_kernel_times(fhe_engine *eng, double total_ms[2], uint32_t *calls, int r
  * executes them level by level, one batched KS+PBS launch per level.  It is the batched replacement
  * of the per-block rayon loops of the reference's integer layer
  * (integer/server_key/radix_parallel/comparison.rs:10-83, scalar_comparison.rs:104-558).
- * `world` > 1 pads every level's pool region so that ranks can all-gather equal-sized slices. */
+ * With `world` > 1 every PBS has an owner rank; ranks exchange only what another rank consumes (one
+ * all-gather per level that exports anything, see fhe_plan_level_info). */
 typedef struct fhe_plan fhe_plan;
 int fhe_plan_create(fhe_engine *eng, fhe_plan **out);
 /* Engine-less plan: can be built, finalised and exported (levels, LUT accumulators) on a host
@@ -142,24 +145,45 @@ int fhe_plan_lut(fhe_plan *plan, const uint64_t *table, uint32_t *lut);    /* ge
 int fhe_plan_lin(fhe_plan *plan, const uint32_t *nodes, const int32_t *coeffs, uint32_t n_terms,
                  int64_t constant, uint32_t *node);                        /* unchecked add/scalar ops */
 int fhe_plan_pbs(fhe_plan *plan, uint32_t src, uint32_t lut, uint32_t *node); /* apply_lookup_table */
+/* Value ranges are tracked two-sided: fhe_plan_pbs refuses an input that may be negative (it would
+ * wrap into the padding bit, shortint/engine/client_side.rs:66-74); fhe_plan_pbs_signed declares that
+ * the padding bit is used on purpose and the table is read through its negacyclic extension
+ * f(x - msg*carry) = -f(x).  Both refuse inputs above the parameter set's noise budget (in units of one
+ * nominal ciphertext variance; MaxNoiseLevel::validate, shortint/ciphertext/mod.rs:28-55). */
+int fhe_plan_pbs_signed(fhe_plan *plan, uint32_t src, uint32_t lut, uint32_t *node);
+int fhe_plan_set_noise_budget(fhe_plan *plan, double budget);   /* <= 0: no check */
+/* PBS nodes created from now on run on `rank` (-1: automatic).  Used with world > 1 to keep a slice of
+ * the work and its first reduction levels on one GPU. */
+int fhe_plan_set_owner_hint(fhe_plan *plan, int rank);
 int fhe_plan_output(fhe_plan *plan, uint32_t node);
 int fhe_plan_finalize(fhe_plan *plan, uint32_t world);
 /* info[6] = {n_inputs, n_outputs, n_levels, n_pbs, pool_slots, world} */
 int fhe_plan_info(const fhe_plan *plan, uint32_t info[6]);
-/* info[4] = {jobs, pool_base, jobs_per_rank, n_terms}; level == n_levels describes the output gather */
-int fhe_plan_level_info(const fhe_plan *plan, uint32_t level, uint32_t info[4]);
-/* CSR description of a level (any pointer may be NULL): off[jobs+1], src/coeff[n_terms] (src = pool
- * slot), cst[jobs] (already scaled by delta), lut[jobs] */
+/* info[4] = {largest PBS-input noise in the plan (nominal variances), the budget, log2 of the modelled
+ * failure probability of that worst PBS, ciphertexts a rank receives over all all-gathers} */
+int fhe_plan_noise_info(const fhe_plan *plan, double info[4]);
+/* out[6] = {V_pbs, V_ks, V_ms (variances, torus = 1), delta/2, default budget, log2 p_fail at it} */
+int fhe_noise_model(const fhe_params_t *params, double out[6]);
+/* Pool layout of a level.  Every rank runs its own jobs [job_lo, job_hi) of the level (rank_info) and
+ * writes job job_lo + i to pool slot local_base + i; if e_max > 0 the level ends with an all-gather of
+ * the first e_max slots of every rank's local region into [recv_base, recv_base + world * e_max).
+ * info[8] = {jobs, local_base, local_size, e_max, recv_base, n_terms, 0, 0}; level == n_levels describes
+ * the output gather (jobs, n_terms only). */
+int fhe_plan_level_info(const fhe_plan *plan, uint32_t level, uint32_t info[8]);
+/* info[3] = {job_lo, job_hi, n_export} */
+int fhe_plan_level_rank_info(const fhe_plan *plan, uint32_t level, uint32_t rank, uint32_t info[3]);
+/* CSR description of a level in job order (any pointer may be NULL): off[jobs+1], src/coeff[n_terms]
+ * (src = pool slot), cst[jobs] (already scaled by delta), lut[jobs] */
 int fhe_plan_export_level(const fhe_plan *plan, uint32_t level, uint32_t *off, uint32_t *src,
                           int32_t *coeff, uint64_t *cst, uint32_t *lut);
-/* single GPU, host buffers: inputs n_inputs x (kN+1), outputs n_outputs x (kN+1) */
 /* plan-local LUT ids (the `lut` arrays above) and their accumulators ((k+1)*N u64) */
 int fhe_plan_lut_count(const fhe_plan *plan, uint32_t *count);
 int fhe_plan_export_lut(const fhe_plan *plan, uint32_t lut, uint64_t *accumulator);
+/* single GPU, host buffers: inputs n_inputs x (kN+1), outputs n_outputs x (kN+1) */
 int fhe_plan_run(fhe_plan *plan, const uint64_t *inputs, uint64_t *outputs);
-/* multi-GPU building blocks (device pool of pool_slots big LWEs; inputs live in slots [0, n_inputs)):
- * run jobs [lo, hi) of one level into their pool slots; gather the outputs from a complete pool. */
-int fhe_plan_run_level_slice_dev(fhe_plan *plan, uint64_t *d_pool, uint32_t level, uint32_t lo, uint32_t hi);
+/* multi-GPU building blocks (device pool of pool_slots big LWEs; inputs live in slots [0, n_inputs) on
+ * every rank): run `rank`'s jobs of one level; gather the outputs once the last level is through. */
+int fhe_plan_run_level_rank_dev(fhe_plan *plan, uint64_t *d_pool, uint32_t level, uint32_t rank);
 int fhe_plan_gather_outputs_dev(fhe_plan *plan, const uint64_t *d_pool, uint64_t *d_out);
 
 /* ---- FheString operations --------------------------------------------------------------------- */

@@ -1,0 +1,108 @@
+"""Noise budget of the PBS inputs the string layer builds, measured on the GPU path.
+
+For PARAM_MESSAGE_2_CARRY_2_KS_PBS: take nominal-noise ciphertexts (outputs of an identity PBS), form
+  packed    lo_a + 4 hi_a - lo_b - 4 hi_b   (packed_pair_eq / packed compare_sign: squared norm 34)
+  bivariate 4 a + b                         (the reference's bivariate packing, bivariate_pbs.rs:167-182: 17)
+  sum15     15 PBS outputs added            (are_all_comparisons_block_true, scalar_comparison.rs:155-176: 15)
+keyswitch them on the GPU, and measure on the host (with the secret keys) the phase error of the small
+LWE before and after the modulus switch to 2N (fft_impl/common.rs:26-43) -- the quantity that decides
+whether the blind rotation lands in the right box.  Prints one JSON object; tests/test_gpu_noise.py
+asserts on the same numbers.
+
+    python scripts/noise_budget.py [samples]
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "fhe-string-bounty_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+
+def log2_pfail(std, bound):
+    """log2 of the two-sided Gaussian tail P(|e| > bound)."""
+    z = bound / std
+    p = math.erfc(z / math.sqrt(2.0))
+    if p > 0:
+        return math.log2(p)
+    # asymptotic expansion for tails below the double range
+    return (-(z * z) / 2 - math.log(z * math.sqrt(math.pi / 2))) / math.log(2)
+
+
+def measure(ks, eng, samples=8192, chunk=1024, seed=0x5EED0004):
+    """Returns {shape: {"norm2": ..., "std_ks": ..., "std_ms": ..., "log2_pfail": ...}, "pbs_out_std": ...}
+    (stds as fractions of the torus)."""
+    import oracle as O
+    p = ks.params
+    logN = p.N.bit_length() - 1
+    M = p.msg_mod
+    delta = p.delta
+    lut, _ = ks.sk.generate_lookup_table(lambda x: x)
+    ident = eng.upload_lut(lut)
+    sel = np.flatnonzero(ks.ck.small_sk.astype(np.uint64) == 1)
+    shapes = {
+        "packed_34": ([1, M, -1, -M], 34),
+        "bivariate_17": ([M, 1, 0, 0], 17),
+    }
+    errs = {k: {"ks": [], "ms": []} for k in list(shapes) + ["sum15_15"]}
+    pbs_err = []
+    rng = np.random.default_rng(seed)
+    done = 0
+    while done < samples:
+        S = min(chunk, samples - done)
+        msgs = rng.integers(0, M, size=(4, S))
+        fresh = ks.ck.encrypt_many(msgs.reshape(-1), O.Rng(seed, done + 1))
+        nominal = eng.apply_lookup_table(fresh, np.full(4 * S, ident, dtype=np.uint32))   # noise level 1
+        if done == 0:   # PBS output noise itself (big key), on a subset
+            sub = nominal[:256]
+            ph = np.array([ks.ck.decrypt_plaintext(c) for c in sub], dtype=np.uint64)
+            with np.errstate(over="ignore"):
+                e = (ph - msgs.reshape(-1)[:256].astype(np.uint64) * np.uint64(delta)).astype(np.int64)
+            pbs_err = e.astype(np.float64) / 2.0**64
+        jobs, values = {}, {}
+        for name, (co, _) in shapes.items():
+            jobs[name] = [([(r * S + i, c) for r, c in enumerate(co) if c], 0) for i in range(S)]
+            values[name] = sum(c * msgs[r] for r, c in enumerate(co))
+        # 15 nominal ciphertexts added (values 0/1 would be the real use; the noise does not care)
+        g = (4 * S) // 15
+        jobs["sum15_15"] = [([(15 * i + t, 1) for t in range(15)], 0) for i in range(g)]
+        values["sum15_15"] = msgs.reshape(-1)[: 15 * g].reshape(g, 15).sum(axis=1)
+        for name in jobs:
+            lin = eng.lincomb(nominal, jobs[name])
+            small = eng.keyswitch(lin)
+            want = (values[name].astype(np.int64).astype(np.uint64) * np.uint64(delta))
+            with np.errstate(over="ignore"):
+                phase = small[:, -1] - small[:, sel].sum(axis=1, dtype=np.uint64)
+                e_ks = (phase - want).astype(np.int64).astype(np.float64) / 2.0**64
+                # modulus switch of every element to [0, 2N] (common.rs:26-43), phase mod 2N
+                ms = ((small >> np.uint64(64 - logN - 2)) + np.uint64(1)) >> np.uint64(1)
+                ph_ms = (ms[:, -1].astype(np.int64) - ms[:, sel].astype(np.int64).sum(axis=1)) % (2 * p.N)
+                want_ms = (want.astype(np.float64) / 2.0**64) * (2 * p.N)
+                d = (ph_ms - want_ms + p.N) % (2 * p.N) - p.N
+                e_ms = d / (2 * p.N)
+            errs[name]["ks"].append(e_ks)
+            errs[name]["ms"].append(e_ms)
+        done += S
+    half_box = (delta / 2) / 2.0**64
+    out = {"params": p.name, "samples": samples, "half_box": half_box,
+           "pbs_out_std": float(np.std(pbs_err)), "pbs_out_std_log2_u64": float(np.log2(np.std(pbs_err)) + 64)}
+    for name in errs:
+        ks_e, ms_e = np.concatenate(errs[name]["ks"]), np.concatenate(errs[name]["ms"])
+        out[name] = {"norm2_sq": int(name.rsplit("_", 1)[1]), "n": int(ks_e.size),
+                     "std_after_ks": float(ks_e.std()), "std_after_ms": float(ms_e.std()),
+                     "mean_after_ms": float(ms_e.mean()), "max_abs_after_ms": float(np.abs(ms_e).max()),
+                     "log2_pfail_gauss": log2_pfail(float(ms_e.std()), half_box)}
+    return out
+
+
+if __name__ == "__main__":
+    import oracle as O
+    from conftest import gpu_engine, keyset
+    ks = keyset(O.PARAM_MESSAGE_2_CARRY_2_KS_PBS)
+    eng = gpu_engine(ks)
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    print(json.dumps(measure(ks, eng, n), indent=1))

@@ -21,6 +21,7 @@ class OracleBackend:
         n_levels = plan.info()["n_levels"]
         self.levels = [plan.export_level(l) for l in range(n_levels + 1)]
         self.luts = plan.export_luts()
+        self.plan = plan
         self.sk = sk
         self.group = group
         self.big = sk.params.big_size
@@ -31,21 +32,24 @@ class OracleBackend:
     def load_inputs(self, pool, inputs, n_inputs):
         pool[:n_inputs] = np.asarray(inputs, dtype=np.uint64).reshape(n_inputs, self.big)
 
-    def run_level_slice(self, pool, level, lo, hi):
+    def run_level(self, pool, level, rank):
         lv = self.levels[level]
-        jobs = list(range(lo, hi))
+        ri = self.plan.level_rank_info(level, rank)
+        jobs = list(range(ri["job_lo"], ri["job_hi"]))
+        if not jobs:
+            return
         staged = lincomb(pool, lv, jobs)
         ids = sorted(set(int(lv["lut"][j]) for j in jobs))
         luts = np.stack([self.luts[i] for i in ids])
         idx = np.array([ids.index(int(lv["lut"][j])) for j in jobs], dtype=np.uint32)
-        pool[lv["base"] + lo: lv["base"] + hi] = self.sk.apply_lookup_table_batch(staged, luts, idx)
+        pool[lv["local_base"]: lv["local_base"] + len(jobs)] = self.sk.apply_lookup_table_batch(staged, luts, idx)
 
-    def all_gather(self, pool, base, per_rank, rank, world):
+    def all_gather(self, pool, local_base, e_max, recv_base, world):
         import torch
         import torch.distributed as dist
-        region = torch.from_numpy(pool[base: base + per_rank * world].view(np.int64))
-        own = region[rank * per_rank: (rank + 1) * per_rank].clone()
-        dist.all_gather_into_tensor(region, own, group=self.group)
+        recv = torch.from_numpy(pool[recv_base: recv_base + e_max * world].view(np.int64))
+        own = torch.from_numpy(pool[local_base: local_base + e_max].view(np.int64)).clone()
+        dist.all_gather_into_tensor(recv, own, group=self.group)
 
     def gather_outputs(self, pool, n_outputs):
         lv = self.levels[-1]

@@ -109,8 +109,8 @@ def test_replace(toy_k1, s, frm, to):
 
 
 def test_p22_replace_to_lower_strip_64_chars(p22):
-    """BASELINE.json config 5 flavour on the real parameter set (PARAM_MESSAGE_2_CARRY_2; the
-    reference's 4_4 set has N = 32768 which this round's kernels do not cover -- DESIGN.md)."""
+    """The config-5 operations on PARAM_MESSAGE_2_CARRY_2 (4 blocks per char); config 5 itself --
+    1024 chars on the reference's PARAM_MESSAGE_4_CARRY_4, N = 32768 -- is tests/test_gpu_config5.py."""
     import fhestr
     ops = _ops(p22)
     P = gpu_engine(p22).params
@@ -201,7 +201,7 @@ def test_sharded_runner_gpu_backend_single_rank(toy_k1):
         # exercise the collective itself on a level region
         pool = backend.alloc_pool(plan.info()["pool_slots"])
         lv = plan.level_info(0)
-        backend.all_gather(pool, lv["base"], lv["per_rank"], 0, 1)
+        backend.all_gather(pool, lv["local_base"], 1, lv["local_base"] + lv["local_size"], 1)
         torch.cuda.synchronize()
     finally:
         eng.set_stream(None)
