@@ -110,7 +110,12 @@ def bench_strings(fhestr, eng, ck, P, rank, world, local_rank, reps=3):
         ms = timings["resident"]
         info = plan.info()
         out[name] = {"ms_per_op": ms, "ms_per_op_inputs_from_host": timings["from_host"], "n_pbs": info["n_pbs"],
-                     "levels": info["n_levels"], "correct": bool(ok), "pbs_per_s": info["n_pbs"] / (ms * 1e-3)}
+                     "levels": info["n_levels"], "correct": bool(ok), "pbs_per_s": info["n_pbs"] / (ms * 1e-3),
+                     # what the ranks exchange: only ciphertexts another rank consumes
+                     "sharded_over": world, "collectives_per_op": runner.collectives,
+                     "gathered_lwes_per_rank": runner.gathered_lwes, "gathered_bytes_per_rank": runner.gathered_bytes,
+                     "worst_pbs_input_noise": plan.noise_info()["max_pbs_input_noise"],
+                     "noise_budget": plan.noise_info()["budget"]}
         plan.close()
     eng.set_stream(None)
     return out
@@ -434,6 +439,10 @@ def main():
         dog.cancel()
         if rank == 0:
             rec["string_ops"] = string_ops
+            # first-class: FheString ms/op with every level's jobs sharded over the `world` ranks
+            for key, field in (("eq_256_enc_enc", "fhestring_eq_256_ms"), ("contains_16_in_256_enc_enc", "fhestring_contains_16_in_256_ms")):
+                if isinstance(string_ops.get(key), dict):
+                    rec[field] = string_ops[key]["ms_per_op"]
 
     if rank == 0 and world == 1 and not args.no_strings:
         try:

@@ -3,6 +3,7 @@
 // every entry point catches everything and returns 0/1 (c_api/utils.rs:3-12), out-pointers are
 // nulled first so unchecked failures are loud (c_api/shortint/server_key/pbs.rs:24-29).
 #include <exception>
+#include <string>
 #include <vector>
 
 #include "engine.h"
@@ -476,14 +477,19 @@ int fhe_plan_gather_outputs_dev(fhe_plan* p, const uint64_t* d_pool, uint64_t* d
     API_END
 }
 
-// one-call FheString operations (host buffers)
-static int str_op(fhe_engine* eng, const char* op, const uint64_t* a, uint32_t a_cap, const uint64_t* b,
-                  uint32_t b_cap, const uint8_t* clear, uint32_t clear_len, uint64_t* out) {
+// one-call FheString operations (host buffers): up to three encrypted operands, each `caps[i]` characters
+static int str_op_parts(fhe_engine* eng, const std::string& op, const uint64_t* const* operands, const uint32_t* caps,
+                        uint32_t n_operands, const uint8_t* clear, uint32_t clear_len, uint64_t* out) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(a); CHECK_PTR(out);
+    CHECK_PTR(eng); CHECK_PTR(out);
+    uint32_t a_cap = caps[0], b_cap = 0;
+    for (uint32_t i = 0; i < n_operands; i++) {
+        CHECK_PTR(operands[i]);
+        if (i) b_cap += caps[i];
+    }
     // plan cache, most recently used first (at most STR_PLAN_CACHE entries)
     constexpr size_t STR_PLAN_CACHE = 8;
-    std::string key = std::string(op) + "|" + std::to_string(a_cap) + "|" + std::to_string(b_cap) + "|";
+    std::string key = op + "|" + std::to_string(a_cap) + "|" + std::to_string(b_cap) + "|";
     if (clear) key.append(reinterpret_cast<const char*>(clear), clear_len);
     fhe_plan* plan = nullptr;
     auto& cache = eng->str_plans;
@@ -494,18 +500,26 @@ static int str_op(fhe_engine* eng, const char* op, const uint64_t* a, uint32_t a
             break;
         }
     if (!plan) {
-        if (fhe_str_plan_create(eng, op, a_cap, b_cap, clear, clear_len, 1, &plan)) return 1;
+        if (fhe_str_plan_create(eng, op.c_str(), a_cap, b_cap, clear, clear_len, 1, &plan)) return 1;
         cache.insert(cache.begin(), {key, plan});
         if (cache.size() > STR_PLAN_CACHE) {
             fhe_plan_destroy(cache.back().second);
             cache.pop_back();
         }
     }
-    const uint32_t bpc = plan->c->n_inputs() / (a_cap + (b ? b_cap : 0));      // blocks per character
-    const uint64_t* parts[2] = {a, b};
-    const uint32_t counts[2] = {a_cap * bpc, b ? b_cap * bpc : 0};
-    return plan->c->run_host_parts(parts, counts, 2, out);
+    const uint32_t bpc = plan->c->n_inputs() / (a_cap + b_cap);      // blocks per character
+    uint32_t counts[3] = {0, 0, 0};
+    for (uint32_t i = 0; i < n_operands; i++) counts[i] = caps[i] * bpc;
+    return plan->c->run_host_parts(operands, counts, n_operands, out);
     API_END
+}
+
+static int str_op(fhe_engine* eng, const char* op, const uint64_t* a, uint32_t a_cap, const uint64_t* b,
+                  uint32_t b_cap, const uint8_t* clear, uint32_t clear_len, uint64_t* out) {
+    if (!a) return fail("null pointer: a");
+    const uint64_t* operands[2] = {a, b};
+    const uint32_t caps[2] = {a_cap, b_cap};
+    return str_op_parts(eng, op, operands, caps, b ? 2 : 1, clear, clear_len, out);
 }
 
 #define STR_BINARY(name)                                                                              \
@@ -531,6 +545,34 @@ STR_BINARY(le)
 STR_BINARY(gt)
 STR_BINARY(ge)
 STR_BINARY(concat)
+
+/* encrypted (zero padded) pattern: out = 1 + a_cap * blocks LWEs, stripped bit first */
+int fhe_str_strip_prefix(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, const uint64_t* pat, uint32_t pat_cap, uint64_t* out) {
+    if (!pat) return fail("null pointer: pat");
+    return str_op(eng, "strip_prefix", a, a_cap, pat, pat_cap, nullptr, 0, out);
+}
+int fhe_str_strip_suffix(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, const uint64_t* pat, uint32_t pat_cap, uint64_t* out) {
+    if (!pat) return fail("null pointer: pat");
+    return str_op(eng, "strip_suffix", a, a_cap, pat, pat_cap, nullptr, 0, out);
+}
+int fhe_str_replace_general(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, const uint64_t* from, uint32_t from_cap,
+                            const uint64_t* to, uint32_t to_cap, uint32_t out_cap, uint64_t* out) {
+    if (!a) return fail("null pointer: a");
+    if (!from || from_cap == 0) return fail("replace: `from` needs a capacity of at least one character");
+    if (to_cap && !to) return fail("null pointer: to");
+    const std::string op = "replace:" + std::to_string(from_cap) + ":" + std::to_string(out_cap);
+    const uint64_t* operands[3] = {a, from, to};
+    const uint32_t caps[3] = {a_cap, from_cap, to_cap};
+    return str_op_parts(eng, op, operands, caps, to_cap ? 3 : 2, nullptr, 0, out);
+}
+int fhe_str_replace_clear_general(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, const uint8_t* from, uint32_t from_len,
+                                  const uint8_t* to, uint32_t to_len, uint32_t out_cap, uint64_t* out) {
+    if ((from_len && !from) || (to_len && !to)) return fail("null pointer: from / to");
+    std::vector<uint8_t> both(from, from + from_len);
+    both.insert(both.end(), to, to + to_len);
+    const std::string op = "replace_clear:" + std::to_string(from_len) + ":" + std::to_string(out_cap);
+    return str_op(eng, op.c_str(), a, a_cap, nullptr, 0, both.data(), (uint32_t)both.size(), out);
+}
 
 int fhe_str_repeat_clear(fhe_engine* eng, const uint64_t* a, uint32_t a_cap, uint32_t count, uint64_t* out) {
     if (count == 0 || count > 255) return fail("repeat: count must be in 1..255");

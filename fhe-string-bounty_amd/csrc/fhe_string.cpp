@@ -23,6 +23,7 @@ namespace fhe {
 struct Str {
     uint32_t cap = 0;
     std::vector<std::vector<uint32_t>> ch;   // [char][block] node ids
+    std::vector<uint32_t> occ;               // optional, [char]: 0/1 node "this slot holds a character"
 };
 
 class StrOps {
@@ -34,10 +35,41 @@ public:
         while ((1u << bits_per_block) < M) bits_per_block++;
         bpc = 8 / bits_per_block;
         ok = (1u << bits_per_block) == M && 8 % bits_per_block == 0 && T / M >= M;
+        world = c.build_world();
     }
     Circuit& c;
-    uint32_t M, T, bits_per_block, bpc;
+    uint32_t M, T, bits_per_block, bpc, world;
     bool ok;
+
+    // ---- multi-GPU: which rank owns the work on element idx of `total` (contiguous slices) ----
+    int owner_for(uint32_t idx, uint32_t total) const { return world > 1 && total ? (int)((uint64_t)idx * world / total) : -1; }
+    struct Scope {   // PBS nodes created while alive belong to `rank` (no-op for rank < 0)
+        Circuit& c; int prev;
+        Scope(Circuit& c, int rank) : c(c), prev(c.owner_hint()) { if (rank >= 0) c.set_owner_hint(rank); }
+        ~Scope() { c.set_owner_hint(prev); }
+    };
+    // ---- noise: split a sum into pieces one lookup may take (value bound max_terms, noise budget) ----
+    double budget() const { return c.noise_budget() > 0 ? c.noise_budget() : 1e300; }
+    std::vector<std::vector<Term>> term_groups(const std::vector<Term>& terms, size_t max_terms) const {
+        std::vector<std::vector<Term>> out;
+        double nu = 0;
+        for (const Term& t : terms) {
+            const double add = (double)t.coeff * t.coeff * c.node(t.node).noise;
+            if (out.empty() || out.back().size() >= max_terms || (nu + add > budget() && !out.back().empty())) {
+                out.emplace_back();
+                nu = 0;
+            }
+            out.back().push_back(t);
+            nu += add;
+        }
+        return out;
+    }
+    bool is_trivial(uint32_t node, int64_t* value = nullptr) const {
+        const Node& n = c.node(node);
+        if (n.kind != Node::LIN || !n.terms.empty()) return false;
+        if (value) *value = n.cst;
+        return true;
+    }
     // Encrypted-vs-encrypted comparisons: true = compare two blocks per PBS (see packed_pair_eq),
     // false = the reference's one-bivariate-PBS-per-block shape (comparison.rs:10-33).
     bool packed_compare = true;
@@ -54,40 +86,42 @@ public:
     uint32_t clear_block(uint8_t v, uint32_t b) const { return (v >> (b * bits_per_block)) & (M - 1); }
 
     // ---- reductions of 0/1 blocks ----
-    // are_all_comparisons_block_true (scalar_comparison.rs:147-191)
-    uint32_t all_true(std::vector<uint32_t> bits) {
-        if (bits.empty()) return c.trivial(1);
-        const uint32_t max_value = T - 1;
-        while (bits.size() > 1) {
-            std::vector<uint32_t> next;
-            for (size_t i = 0; i < bits.size(); i += max_value) {
-                const size_t len = std::min<size_t>(max_value, bits.size() - i);
-                std::vector<Term> terms;
-                for (size_t j = 0; j < len; j++) terms.push_back({bits[i + j], 1});
-                const uint32_t l = c.lut_fn([len](uint64_t x) { return (uint64_t)(x == len); });
-                next.push_back(c.pbs(c.lin(terms), l));
-            }
-            bits.swap(next);
-        }
-        return bits[0];
-    }
-    // is_at_least_one_comparisons_block_true (scalar_comparison.rs:200-233)
-    uint32_t any_true(std::vector<uint32_t> bits) {
-        if (bits.empty()) return c.trivial(0);
-        const uint32_t max_value = T - 1;
+    // are_all_comparisons_block_true (scalar_comparison.rs:147-191) / is_at_least_one_comparisons_block_true
+    // (scalar_comparison.rs:200-233) on one rank: chunks of up to msg*carry - 1 bits (fewer if the
+    // noise budget says so) are summed and sent through `x == chunk_len` / `x != 0`, repeated to one bit
+    uint32_t reduce_local(std::vector<uint32_t> bits, bool all) {
         const uint32_t nz = c.lut_fn([](uint64_t x) { return (uint64_t)(x != 0); });
         while (bits.size() > 1) {
+            std::vector<Term> terms;
+            for (uint32_t b : bits) terms.push_back({b, 1});
             std::vector<uint32_t> next;
-            for (size_t i = 0; i < bits.size(); i += max_value) {
-                const size_t len = std::min<size_t>(max_value, bits.size() - i);
-                std::vector<Term> terms;
-                for (size_t j = 0; j < len; j++) terms.push_back({bits[i + j], 1});
-                next.push_back(c.pbs(c.lin(terms), nz));
+            for (const auto& g : term_groups(terms, T - 1)) {
+                const size_t len = g.size();
+                const uint32_t l = all ? c.lut_fn([len](uint64_t x) { return (uint64_t)(x == len); }) : nz;
+                next.push_back(c.pbs(c.lin(g), l));
             }
             bits.swap(next);
         }
         return bits[0];
     }
+    // The same over several ranks: every rank first reduces the bits it owns to ONE block,
+    // only those blocks travel (one all-gather), and the last PBS combines them.
+    uint32_t reduce_bits(const std::vector<uint32_t>& bits, bool all) {
+        if (bits.empty()) return c.trivial(all ? 1 : 0);
+        if (world <= 1 || c.owner_hint() >= 0) return reduce_local(bits, all);
+        std::map<int, std::vector<uint32_t>> by_owner;
+        for (uint32_t b : bits) by_owner[c.owner_of(b)].push_back(b);
+        if (by_owner.size() == 1 && by_owner.begin()->first < 0) return reduce_local(bits, all);
+        std::vector<uint32_t> partial;
+        for (auto& kv : by_owner) {
+            if (kv.first < 0) { partial.insert(partial.end(), kv.second.begin(), kv.second.end()); continue; }
+            Scope sc(c, kv.first);
+            partial.push_back(reduce_local(kv.second, all));
+        }
+        return reduce_local(partial, all);
+    }
+    uint32_t all_true(const std::vector<uint32_t>& bits) { return reduce_bits(bits, true); }
+    uint32_t any_true(const std::vector<uint32_t>& bits) { return reduce_bits(bits, false); }
 
     // ---- block-level comparisons ----
     // bivariate LUT on lhs*M + rhs (bivariate_pbs.rs:71-96,167-182)
@@ -108,14 +142,21 @@ public:
         return c.pbs(c.lin({{lo_a, 1}, {hi_a, (int32_t)M}, {lo_b, -1}, {hi_b, -(int32_t)M}}), l, /*signed_input=*/true);
     }
     // equality bits of two encrypted chars: bpc bits (reference shape) or bpc/2 bits (packed)
+    bool packed_pair_fits(uint32_t lo_a, uint32_t hi_a, uint32_t lo_b, uint32_t hi_b) const {
+        const double m2 = (double)M * M;
+        return c.node(lo_a).noise + c.node(lo_b).noise + m2 * (c.node(hi_a).noise + c.node(hi_b).noise) <= budget();
+    }
     void char_eq_bits(const std::vector<uint32_t>& x, const std::vector<uint32_t>& y, std::vector<uint32_t>& out) {
-        if (packed_compare && bpc % 2 == 0) {
+        // packed form only where its 2(1 + M^2) nominal variances fit the parameter set's noise budget
+        // (noise_model.h); otherwise the reference's bivariate shape, M^2 + 1
+        bool packed = packed_compare && bpc % 2 == 0;
+        for (uint32_t k = 0; packed && k + 1 < bpc; k += 2) packed = packed_pair_fits(x[k], x[k + 1], y[k], y[k + 1]);
+        if (packed) {
             for (uint32_t k = 0; k + 1 < bpc; k += 2) out.push_back(packed_pair_eq(x[k], x[k + 1], y[k], y[k + 1]));
         } else {
             for (uint32_t k = 0; k < bpc; k++) out.push_back(block_eq(x[k], y[k], true));
         }
     }
-    uint32_t eq_bits_per_char() const { return (packed_compare && bpc % 2 == 0) ? bpc / 2 : bpc; }
     // pack_block_chunk + scalar LUT (scalar_comparison.rs:104-138,312-336,431-452): two blocks of a
     // char packed as hi*M + lo, compared with the clear value packed the same way.
     uint32_t packed_scalar_cmp(uint32_t lo, uint32_t hi, uint32_t clear, bool want_equal) {
@@ -156,6 +197,7 @@ public:
         const uint32_t n = std::max(a.cap, b.cap);
         std::vector<uint32_t> bits;
         for (uint32_t i = 0; i < n; i++) {
+            Scope sc(c, owner_for(i, n));   // a contiguous slice of the characters per rank
             const auto* x = ch_or_null(a, i);
             const auto* y = ch_or_null(b, i);
             if (x && y) {
@@ -174,7 +216,10 @@ public:
         for (uint32_t i = a.cap; i < len; i++)
             if (clear[i] != 0) return c.trivial(want_equal ? 0 : 1);   // longer than the capacity
         std::vector<uint32_t> bits;
-        for (uint32_t i = 0; i < a.cap; i++) char_scalar_bits(a.ch[i], i < len ? clear[i] : 0, want_equal, bits);
+        for (uint32_t i = 0; i < a.cap; i++) {
+            Scope sc(c, owner_for(i, a.cap));
+            char_scalar_bits(a.ch[i], i < len ? clear[i] : 0, want_equal, bits);
+        }
         return want_equal ? all_true(bits) : any_true(bits);
     }
 
@@ -185,10 +230,9 @@ public:
         for (uint32_t i = 0; i < pat.cap; i++) z.push_back(char_is_zero(pat.ch[i]));
         return z;
     }
-    // sum of the bpc block-equality bits of (s[ci], pat[pi]); s beyond its capacity is null.
-    // returns a LIN node with value in [0, bpc] (bpc == chars equal)
-    uint32_t char_eq_sum(const Str& s, uint32_t ci, const Str& pat, uint32_t pi,
-                         std::map<std::pair<uint32_t, uint32_t>, uint32_t>& memo) {
+    // sum of the block-equality bits of (s[ci], pat[pi]) and how many bits that is (n: all equal)
+    std::pair<uint32_t, uint32_t> char_eq_sum(const Str& s, uint32_t ci, const Str& pat, uint32_t pi,
+                                              std::map<std::pair<uint32_t, uint32_t>, std::pair<uint32_t, uint32_t>>& memo) {
         auto key = std::make_pair(ci, pi);
         auto it = memo.find(key);
         if (it != memo.end()) return it->second;
@@ -196,24 +240,24 @@ public:
         char_eq_bits(s.ch[ci], pat.ch[pi], bits);
         std::vector<Term> terms;
         for (uint32_t bit : bits) terms.push_back({bit, 1});
-        return memo[key] = c.lin(terms);
+        return memo[key] = std::make_pair(c.lin(terms), (uint32_t)bits.size());
     }
     // t = [pat[pi] == 0] OR [s[ci] == pat[pi]]  (prefix-style match: pattern padding matches anything)
     // q = [s[ci] == pat[pi]]                    (exact match incl. padding)
     uint32_t char_match(const Str& s, uint32_t ci, const Str& pat, uint32_t pi, const std::vector<uint32_t>& z,
-                        bool padding_wildcard, std::map<std::pair<uint32_t, uint32_t>, uint32_t>& sums,
+                        bool padding_wildcard, std::map<std::pair<uint32_t, uint32_t>, std::pair<uint32_t, uint32_t>>& sums,
                         std::map<std::pair<uint32_t, uint32_t>, uint32_t>& memo) {
         if (ci >= s.cap) return z[pi];   // null char: equal iff pat[pi] == 0 (both readings)
         auto key = std::make_pair(ci, pi);
         auto it = memo.find(key);
         if (it != memo.end()) return it->second;
-        const uint32_t sum = char_eq_sum(s, ci, pat, pi, sums);
-        const uint32_t n = eq_bits_per_char();
+        const auto sn = char_eq_sum(s, ci, pat, pi, sums);
+        const uint32_t sum = sn.first, n = sn.second;
         uint32_t r;
         if (padding_wildcard) {
-            // value = eq_sum + (n+1)*z  ->  match iff value >= n
+            // value = eq_sum + n*z in [0, 2n]  ->  match iff value >= n (z = 1, or all n bits set)
             const uint32_t l = c.lut_fn([n](uint64_t x) { return (uint64_t)(x >= n); });
-            r = c.pbs(c.lin({{sum, 1}, {z[pi], (int32_t)(n + 1)}}), l);
+            r = c.pbs(c.lin({{sum, 1}, {z[pi], (int32_t)n}}), l);
         } else {
             const uint32_t l = c.lut_fn([n](uint64_t x) { return (uint64_t)(x == n); });
             r = c.pbs(sum, l);
@@ -225,10 +269,12 @@ public:
     std::vector<uint32_t> window_matches(const Str& s, const Str& pat, uint32_t n_off, bool padding_wildcard,
                                          bool need_end = false) {
         std::vector<uint32_t> z = pattern_zero_bits(pat);
-        std::map<std::pair<uint32_t, uint32_t>, uint32_t> sums, memo;
+        std::map<std::pair<uint32_t, uint32_t>, std::pair<uint32_t, uint32_t>> sums;
+        std::map<std::pair<uint32_t, uint32_t>, uint32_t> memo;
         std::map<uint32_t, uint32_t> s_zero;
         std::vector<uint32_t> match;
         for (uint32_t o = 0; o < n_off; o++) {
+            Scope sc(c, owner_for(o, n_off));   // a contiguous slice of the offsets per rank
             std::vector<uint32_t> bits;
             for (uint32_t i = 0; i < pat.cap; i++)
                 bits.push_back(char_match(s, o + i, pat, i, z, padding_wildcard, sums, memo));
@@ -246,6 +292,7 @@ public:
         std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> memo;   // (char, byte) -> bits
         std::vector<uint32_t> match;
         for (uint32_t o = 0; o < n_off; o++) {
+            Scope sc(c, owner_for(o, n_off));
             std::vector<uint32_t> bits;
             for (uint32_t i = 0; i < len; i++) {
                 auto key = std::make_pair(o + i, (uint32_t)pat[i]);
@@ -332,30 +379,23 @@ public:
         if (from_end) std::reverse(first.begin(), first.end());   // one-hot vector back on the original offsets
         out.push_back(found);
         const uint32_t F = T - 1;
+        const uint32_t mm = M;
+        const uint32_t idm = c.lut_fn([mm](uint64_t x) { return x % mm; });
         for (uint32_t d = 0; d < n_digits; d++) {
-            // digit d of the index = sum_o first[o] * digit_d(o): at most one term is non-zero
-            std::vector<uint32_t> parts;
-            for (size_t b = 0; b < first.size(); b += F) {
-                std::vector<Term> terms;
-                for (size_t o = b; o < std::min(first.size(), b + F); o++) {
-                    const uint32_t dig = (uint32_t)((o >> (d * bits_per_block)) & (M - 1));
-                    if (dig) terms.push_back({first[o], (int32_t)dig});
-                }
-                // degree bookkeeping: at most one `first` is 1, so the true bound is M-1
-                if (!terms.empty()) parts.push_back(c.lin(terms, 0, (int64_t)M - 1));
+            // digit d of the index = sum_o first[o] * digit_d(o): at most one term is non-zero, so the
+            // value stays <= M-1 whatever the fan-in; what limits a group is the noise, dig^2 per term
+            std::vector<Term> terms;
+            for (size_t o = 0; o < first.size(); o++) {
+                const uint32_t dig = (uint32_t)((o >> (d * bits_per_block)) & (M - 1));
+                if (dig) terms.push_back({first[o], (int32_t)dig});
             }
-            const uint32_t mm = M;
-            const uint32_t idm = c.lut_fn([mm](uint64_t x) { return x % mm; });
             std::vector<uint32_t> cleaned;
-            for (uint32_t p : parts) cleaned.push_back(c.pbs(p, idm));   // also resets the noise
-            // again at most one part is non-zero: sums stay <= M-1
-            while (cleaned.size() > 1) {
+            for (const auto& g : term_groups(terms, F)) cleaned.push_back(c.pbs(c.lin(g, 0, (int64_t)M - 1), idm));
+            while (cleaned.size() > 1) {   // again at most one part is non-zero
+                std::vector<Term> parts;
+                for (uint32_t p : cleaned) parts.push_back({p, 1});
                 std::vector<uint32_t> next;
-                for (size_t i = 0; i < cleaned.size(); i += F) {
-                    std::vector<Term> terms;
-                    for (size_t j = i; j < std::min(cleaned.size(), i + F); j++) terms.push_back({cleaned[j], 1});
-                    next.push_back(c.pbs(c.lin(terms, 0, (int64_t)M - 1), idm));
-                }
+                for (const auto& g : term_groups(parts, F)) next.push_back(c.pbs(c.lin(g, 0, (int64_t)M - 1), idm));
                 cleaned.swap(next);
             }
             out.push_back(cleaned.empty() ? c.trivial(0) : cleaned[0]);
@@ -382,6 +422,7 @@ public:
         });
         const uint32_t half = bpc / 2;   // blocks per nibble (2 for 2-bit blocks)
         for (uint32_t i = 0; i < s.cap; i++) {
+            Scope sc(c, owner_for(i, s.cap));
             const auto& b = s.ch[i];
             std::vector<Term> lo_terms, hi_terms;
             for (uint32_t k = 0; k < half; k++) {
@@ -413,6 +454,7 @@ public:
         const uint32_t half = bpc / 2;
         std::vector<uint32_t> out;
         for (uint32_t i = 0; i < s.cap; i++) {
+            Scope sc(c, owner_for(i, s.cap));
             std::vector<Term> lo_terms, hi_terms;
             for (uint32_t k = 0; k < half; k++) {
                 lo_terms.push_back({s.ch[i][k], (int32_t)(1u << (k * bits_per_block))});
@@ -425,6 +467,9 @@ public:
     }
     // block * bit (bit in {0,1}) : LUT on bit + 2*block  (noise: 1 + 2*level(block))
     uint32_t gate_block(uint32_t block, uint32_t bit, bool keep_if_set) {
+        int64_t v = 0;
+        if (is_trivial(block, &v) && v == 0) return block;                       // 0 * anything
+        if (is_trivial(bit, &v)) return ((v != 0) == keep_if_set) ? block : c.trivial(0);
         const uint32_t m2 = 2 * M;
         const uint32_t l = c.lut_fn([keep_if_set, m2](uint64_t x) {
             return (uint64_t)((x < m2 && ((x & 1) != 0) == keep_if_set) ? x >> 1 : 0);
@@ -465,12 +510,14 @@ public:
             const uint32_t sh = 1u << t;
             if (sh > s.cap) continue;
             const uint32_t sel = lead[sh - 1];
+            int64_t sv = 0;
+            if (is_trivial(sel, &sv) && sv == 0) continue;       // the indicator is known to be shorter
             Str nxt;
             nxt.cap = s.cap;
             nxt.ch.resize(s.cap);
             std::vector<uint32_t> nlead(s.cap);
             for (uint32_t i = 0; i < s.cap; i++) {
-                for (uint32_t k = 0; k < bpc; k++) {
+                for (size_t k = 0; k < cur.ch[i].size(); k++) {
                     const uint32_t stay = gate_block(cur.ch[i][k], sel, false);
                     if (i + sh < s.cap) nxt.ch[i].push_back(c.lin({{stay, 1}, {gate_block(cur.ch[i + sh][k], sel, true), 1}}, 0, M - 1));
                     else nxt.ch[i].push_back(stay);
@@ -483,6 +530,31 @@ public:
             lead = nlead;
         }
         return cur;
+    }
+    // Concatenation of two left-justified strings whose per-slot occupancy bits are known (occ): the
+    // right operand is parked behind the left one's capacity and shifted left by the left one's free
+    // slots; the occupancy travels as one more block.  No char_is_zero needed.
+    Str concat_occ(const Str& a, const Str& b) {
+        const uint32_t zero = c.trivial(0);
+        Str u;
+        u.cap = a.cap + b.cap;
+        u.ch.resize(u.cap);
+        const size_t nb = a.cap ? a.ch[0].size() : b.ch[0].size();
+        for (uint32_t i = 0; i < a.cap; i++) u.ch[i].assign(nb + 1, zero);
+        for (uint32_t j = 0; j < b.cap; j++) { u.ch[a.cap + j] = b.ch[j]; u.ch[a.cap + j].push_back(b.occ[j]); }
+        std::vector<uint32_t> lead(u.cap, zero);
+        for (uint32_t t = 0; t < a.cap; t++) lead[t] = not_bit(a.occ[a.cap - 1 - t]);   // 1 while in a's free tail
+        Str v = shift_left_by_leading(u, lead);
+        Str out;
+        out.cap = u.cap;
+        out.ch.resize(u.cap);
+        out.occ.resize(u.cap);
+        for (uint32_t i = 0; i < u.cap; i++) {
+            for (size_t k = 0; k < nb; k++)
+                out.ch[i].push_back(i < a.cap ? c.lin({{a.ch[i][k], 1}, {v.ch[i][k], 1}}, 0, M - 1) : v.ch[i][k]);
+            out.occ[i] = i < a.cap ? c.lin({{a.occ[i], 1}, {v.ch[i][nb], 1}}, 0, 1) : v.ch[i][nb];
+        }
+        return out;
     }
     // concat: a ++ b without a's padding.  b is parked behind a's full capacity and shifted left by the
     // number of null characters at the end of a (monotone indicator read from the end of a); the result
@@ -514,49 +586,174 @@ public:
         return t;
     }
 
-    // ---- replace (equal-length pattern and replacement) ----
-    // sel[o] = match[o] and no selected match in the m-1 offsets before it (leftmost, non-overlapping)
-    std::vector<uint32_t> select_non_overlapping(const std::vector<uint32_t>& match, uint32_t m, bool may_overlap) {
-        if (!may_overlap || m <= 1) return match;
-        std::vector<uint32_t> sel(match.size());
-        const uint32_t l = c.lut_fn([](uint64_t x) { return (uint64_t)(x == 1); });
-        for (size_t o = 0; o < match.size(); o++) {
-            std::vector<Term> terms{{match[o], 1}};
-            for (uint32_t j = 1; j < m && j <= o; j++) terms.push_back({sel[o - j], 2});
-            sel[o] = terms.size() == 1 ? match[o] : c.pbs(c.lin(terms, 0, 3), l);   // at most one earlier sel is set
-        }
-        return sel;
+    // ---- replace ----
+    uint32_t and_bits(uint32_t a, uint32_t b) {
+        int64_t v = 0;
+        if (is_trivial(a, &v)) return v ? b : a;
+        if (is_trivial(b, &v)) return v ? a : b;
+        return c.pbs(c.lin({{a, 1}, {b, 1}}), c.lut_fn([](uint64_t x) { return (uint64_t)(x == 2); }));
     }
-    // to: clear bytes (to_clear) or encrypted chars (to_enc, cap == m)
-    Str replace_from_sel(const Str& s, const std::vector<uint32_t>& sel, uint32_t m, const uint8_t* to_clear, const Str* to_enc) {
+    // Occurrence bookkeeping of a replace: which offsets are selected (leftmost, non-overlapping) and
+    // which characters they cover.  An occurrence selected at o - j still runs at o iff j < |from|:
+    // always for a clear / unpadded pattern of length m, and iff nzf[j] = [from[j] != 0] for a padded
+    // encrypted one (nzf == nullptr: unpadded).
+    struct Occurrences {
+        std::vector<uint32_t> sel;     // [offset]
+        std::vector<uint32_t> cover;   // [char] 0/1: inside a selected occurrence
+    };
+    Occurrences occurrences(const std::vector<uint32_t>& match, uint32_t m, uint32_t n_chars, bool may_overlap,
+                            const std::vector<uint32_t>* nzf) {
+        Occurrences oc;
+        std::map<std::pair<uint32_t, uint32_t>, uint32_t> running;   // (offset, j) -> sel[offset] AND nzf[j]
+        auto run_bit = [&](uint32_t o, uint32_t j) {
+            if (!nzf || j == 0) return oc.sel[o];
+            auto key = std::make_pair(o, j);
+            auto it = running.find(key);
+            if (it == running.end()) it = running.emplace(key, and_bits(oc.sel[o], (*nzf)[j])).first;
+            return it->second;
+        };
+        oc.sel.resize(match.size());
+        const uint32_t l3 = c.lut_fn([](uint64_t x) { return (uint64_t)(x == 3); });
+        for (uint32_t o = 0; o < match.size(); o++) {
+            std::vector<uint32_t> blockers;
+            if (may_overlap)
+                for (uint32_t j = 1; j < m && j <= o; j++) blockers.push_back(run_bit(o - j, j));
+            if (blockers.empty()) { oc.sel[o] = match[o]; continue; }
+            // x = 2 match + 1 - (blockers; at most one is set) in {0..3}; selected iff x == 3
+            double nu = 4 * c.node(match[o]).noise;
+            for (uint32_t b : blockers) nu += c.node(b).noise;
+            if (nu > budget()) blockers.assign(1, reduce_local(blockers, false));
+            std::vector<Term> terms{{match[o], 2}};
+            for (uint32_t b : blockers) terms.push_back({b, -1});
+            oc.sel[o] = c.pbs(c.lin(terms, 1, 3), l3);
+        }
+        oc.cover.resize(n_chars);
+        for (uint32_t i = 0; i < n_chars; i++) {
+            std::vector<Term> terms;
+            for (uint32_t j = 0; j < m && j <= i; j++)
+                if (i - j < oc.sel.size()) terms.push_back({run_bit(i - j, j), 1});
+            oc.cover[i] = c.lin(terms, 0, 1);                                  // at most one occurrence covers i
+            if (terms.size() > 8) oc.cover[i] = c.pbs(oc.cover[i], c.lut_fn([](uint64_t x) { return (uint64_t)(x != 0); }));
+        }
+        return oc;
+    }
+    // sel * (clear block v): one lookup on the selector (the linear form v * sel would cost v^2 in noise)
+    uint32_t scale_bit(uint32_t bit, uint32_t v) {
+        if (v == 0) return c.trivial(0);
+        int64_t b = 0;
+        if (is_trivial(bit, &b)) return c.trivial(b ? (int64_t)v : 0);
+        return c.pbs(bit, c.lut_fn([v](uint64_t x) { return (uint64_t)(x == 1 ? v : 0); }));
+    }
+    // Equal lengths (|from| = |to| = m, `to` clear or unpadded encrypted): the string keeps its shape, every
+    // covered character is rewritten in place.
+    Str replace_in_place(const Str& s, const Occurrences& oc, uint32_t m, const uint8_t* to_clear, const Str* to_enc) {
         Str out;
         out.cap = s.cap;
         out.ch.resize(s.cap);
-        std::map<std::pair<uint32_t, uint32_t>, uint32_t> prod;   // (offset, j*bpc+k) -> sel[o] * to[j].block k
         for (uint32_t i = 0; i < s.cap; i++) {
-            std::vector<Term> cover_terms;
-            for (uint32_t j = 0; j < m && j <= i; j++)
-                if (i - j < sel.size()) cover_terms.push_back({sel[i - j], 1});
-            if (cover_terms.empty()) { out.ch[i] = s.ch[i]; continue; }
-            uint32_t cover = c.lin(cover_terms, 0, 1);
-            if (cover_terms.size() > 3) cover = c.pbs(cover, c.lut_fn([](uint64_t x) { return (uint64_t)(x != 0); }));
+            Scope sc(c, owner_for(i, s.cap));
+            if (is_trivial(oc.cover[i])) { out.ch[i] = s.ch[i]; continue; }
             for (uint32_t k = 0; k < bpc; k++) {
-                std::vector<Term> terms{{gate_block(s.ch[i][k], cover, false), 1}};
+                std::vector<Term> terms{{gate_block(s.ch[i][k], oc.cover[i], false), 1}};
+                std::vector<Term> lin_contrib;      // clear `to`: v_j * sel[i - j], cheap while its noise fits
+                double nu = c.node(terms[0].node).noise;
                 for (uint32_t j = 0; j < m && j <= i; j++) {
-                    if (i - j >= sel.size()) continue;
+                    if (i - j >= oc.sel.size()) continue;
                     if (to_clear) {
                         const uint32_t v = clear_block(to_clear[j], k);
-                        if (v) terms.push_back({sel[i - j], (int32_t)v});
+                        if (v) { lin_contrib.push_back({oc.sel[i - j], (int32_t)v}); nu += (double)v * v * c.node(oc.sel[i - j]).noise; }
                     } else {
-                        terms.push_back({gate_block(to_enc->ch[j][k], sel[i - j], true), 1});
+                        terms.push_back({gate_block(to_enc->ch[j][k], oc.sel[i - j], true), 1});
                     }
                 }
-                uint32_t blk = c.lin(terms, 0, M - 1);   // at most one contribution is non-zero
-                int64_t weight = 0;
-                for (const Term& t : terms) weight += t.coeff;
-                if (weight > (int64_t)T - 1) blk = c.pbs(blk, c.lut_fn([this](uint64_t x) { return x % M; }));
-                out.ch[i].push_back(blk);
+                if (nu <= budget()) terms.insert(terms.end(), lin_contrib.begin(), lin_contrib.end());
+                else for (const Term& t : lin_contrib) terms.push_back({scale_bit(t.node, (uint32_t)t.coeff), 1});
+                out.ch[i].push_back(c.lin(terms, 0, M - 1));   // at most one contribution is non-zero
             }
+        }
+        return out;
+    }
+    // Any lengths (clear or encrypted, padded or not): every position becomes a small left-justified
+    // piece -- the replacement if an occurrence is selected there, the character itself if it is kept,
+    // nothing if it is covered -- and the pieces are concatenated pairwise (log2 n rounds of the
+    // occupancy-driven barrel shifter).  Result capacity = s.cap * max(1, |to| capacity), cut / padded
+    // to out_cap.
+    Str replace_general(const Str& s, const Occurrences& oc, const uint8_t* to_clear, uint32_t to_len, const Str* to_enc,
+                        uint32_t out_cap) {
+        const uint32_t w = std::max<uint32_t>(1, to_enc ? to_enc->cap : to_len);
+        const uint32_t zero = c.trivial(0);
+        std::vector<uint32_t> nzt;
+        if (to_enc) for (uint32_t j = 0; j < to_enc->cap; j++) nzt.push_back(not_bit(char_is_zero(to_enc->ch[j])));
+        const uint32_t l2 = c.lut_fn([](uint64_t x) { return (uint64_t)(x == 2); });
+        std::vector<Str> cur;
+        for (uint32_t i = 0; i < s.cap; i++) {
+            Scope sc(c, owner_for(i, s.cap));
+            const bool has_sel = i < oc.sel.size();
+            const uint32_t nz = not_bit(char_is_zero(s.ch[i]));
+            // kept = this slot holds a character that survives: s[i] != 0 and not covered
+            const uint32_t kept = is_trivial(oc.cover[i]) ? nz : c.pbs(c.lin({{nz, 1}, {oc.cover[i], -1}}, 1), l2);
+            Str piece;
+            piece.cap = w;
+            piece.ch.resize(w);
+            piece.occ.resize(w);
+            for (uint32_t j = 0; j < w; j++) {
+                const bool to_slot = has_sel && j < (to_enc ? to_enc->cap : to_len);
+                for (uint32_t k = 0; k < bpc; k++) {
+                    uint32_t contrib = zero;
+                    if (to_slot) contrib = to_enc ? gate_block(to_enc->ch[j][k], oc.sel[i], true)
+                                                  : scale_bit(oc.sel[i], clear_block(to_clear[j], k));
+                    if (j == 0) piece.ch[j].push_back(c.lin({{gate_block(s.ch[i][k], oc.cover[i], false), 1}, {contrib, 1}}, 0, M - 1));
+                    else piece.ch[j].push_back(contrib);
+                }
+                const uint32_t sel_occ = !to_slot ? zero : (to_enc ? and_bits(oc.sel[i], nzt[j]) : oc.sel[i]);
+                piece.occ[j] = j == 0 ? c.lin({{kept, 1}, {sel_occ, 1}}, 0, 1) : sel_occ;
+            }
+            cur.push_back(piece);
+        }
+        return fit(concat_tree(cur), out_cap);
+    }
+    // Empty clear pattern (Rust's str::replace("", to) / bytes.replace(b"", to)): `to` before every
+    // character and after the last one.
+    Str replace_empty_pattern(const Str& s, const uint8_t* to_clear, uint32_t t, uint32_t out_cap) {
+        if (t == 0) return fit(s, out_cap);
+        const uint32_t one = c.trivial(1);
+        std::vector<uint32_t> nz;
+        for (uint32_t i = 0; i < s.cap; i++) nz.push_back(not_bit(char_is_zero(s.ch[i])));
+        std::vector<Str> cur;
+        for (uint32_t i = 0; i <= s.cap; i++) {
+            Scope sc(c, owner_for(std::min(i, s.cap - 1), s.cap));
+            const uint32_t g = i == 0 ? one : nz[i - 1];       // position i is still inside (or right after) the string
+            Str piece;
+            piece.cap = t + (i < s.cap ? 1 : 0);
+            piece.ch.resize(piece.cap);
+            piece.occ.resize(piece.cap);
+            for (uint32_t j = 0; j < t; j++) {
+                for (uint32_t k = 0; k < bpc; k++) piece.ch[j].push_back(scale_bit(g, clear_block(to_clear[j], k)));
+                piece.occ[j] = g;
+            }
+            if (i < s.cap) { piece.ch[t] = s.ch[i]; piece.occ[t] = nz[i]; }
+            cur.push_back(piece);
+        }
+        return fit(concat_tree(cur), out_cap);
+    }
+    Str concat_tree(std::vector<Str> cur) {
+        while (cur.size() > 1) {
+            std::vector<Str> next;
+            for (size_t i = 0; i + 1 < cur.size(); i += 2) next.push_back(concat_occ(cur[i], cur[i + 1]));
+            if (cur.size() & 1) next.push_back(cur.back());
+            cur.swap(next);
+        }
+        return cur[0];
+    }
+    // cut or zero-pad to `cap` characters
+    Str fit(const Str& r, uint32_t cap) {
+        Str out;
+        out.cap = cap;
+        out.ch.resize(cap);
+        const uint32_t zero = c.trivial(0);
+        for (uint32_t i = 0; i < cap; i++) {
+            if (i < r.cap) out.ch[i].assign(r.ch[i].begin(), r.ch[i].begin() + bpc);
+            else out.ch[i].assign(bpc, zero);
         }
         return out;
     }
@@ -621,6 +818,28 @@ public:
             for (uint32_t k = 0; k < bpc; k++)
                 out.ch[i].push_back(i < cut.size() ? gate_block(s.ch[i][k], cut[i], false)
                                                    : gate_block(s.ch[i][k], cut.back(), false));
+        return out;
+    }
+    // strip_prefix with an encrypted (padded) pattern: shift left by the pattern's hidden length iff
+    // the string starts with it -- the barrel shifter's monotone indicator is sel AND [pat[t] != 0]
+    Str strip_prefix(const Str& s, const Str& pat, uint32_t* stripped_bit) {
+        const uint32_t sel = starts_with(s, pat);
+        *stripped_bit = sel;
+        std::vector<uint32_t> lead(s.cap, c.trivial(0));
+        for (uint32_t t = 0; t < std::min(s.cap, pat.cap); t++) lead[t] = and_bits(sel, not_bit(char_is_zero(pat.ch[t])));
+        return shift_left_by_leading(s, lead);
+    }
+    // strip_suffix with an encrypted (padded) pattern: cand[o] = "s[o..] is exactly the pattern"
+    // (window match incl. the end-of-string test); every character from the first such o on is zeroed
+    Str strip_suffix(const Str& s, const Str& pat, uint32_t* stripped_bit) {
+        std::vector<uint32_t> cand = window_matches(s, pat, s.cap + 1, false, true);
+        std::vector<uint32_t> cut = prefix_or(std::vector<uint32_t>(cand.begin(), cand.begin() + s.cap));
+        *stripped_bit = reduce_local({cut.back(), cand[s.cap]}, false);
+        Str out;
+        out.cap = s.cap;
+        out.ch.resize(s.cap);
+        for (uint32_t i = 0; i < s.cap; i++)
+            for (uint32_t k = 0; k < bpc; k++) out.ch[i].push_back(gate_block(s.ch[i][k], cut[i], false));
         return out;
     }
     // ---- lexicographic order (the reference's comparator idea: per-block sign, then pairwise
@@ -692,7 +911,26 @@ public:
 int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t b_cap,
                     const uint8_t* clear, uint32_t clear_len) {
     StrOps s(c);
+    // "name:p1:p2": numeric parameters of the general replace (pattern capacity / length, output capacity)
+    std::vector<uint32_t> op_params;
     std::string op_name = op;
+    {
+        size_t colon = op_name.find(':');
+        if (colon != std::string::npos) {
+            std::string rest = op_name.substr(colon + 1);
+            op_name = op_name.substr(0, colon);
+            size_t pos = 0;
+            while (pos <= rest.size()) {
+                size_t nxt = rest.find(':', pos);
+                if (nxt == std::string::npos) nxt = rest.size();
+                const std::string tok = rest.substr(pos, nxt - pos);
+                if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos || tok.size() > 9)
+                    return fail("bad numeric parameter in string op: " + op);
+                op_params.push_back((uint32_t)std::stoul(tok));
+                pos = nxt + 1;
+            }
+        }
+    }
     const std::string ref_suffix = "_reference";
     for (const char* tail : {"_reference_clear", "_reference"}) {
         const std::string t(tail);
@@ -744,10 +982,10 @@ int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t 
         s.len(a, n_digits, outs);
         for (uint32_t o : outs) c.output(o);
     } else if (base == "strip_prefix" || base == "strip_suffix") {
-        if (!is_clear) return fail(base + " is implemented for clear patterns only");
         uint32_t bit = 0;
-        Str r = base == "strip_prefix" ? s.strip_prefix_clear(a, clear, clear_len, &bit)
-                                       : s.strip_suffix_clear(a, clear, clear_len, &bit);
+        Str r = is_clear ? (base == "strip_prefix" ? s.strip_prefix_clear(a, clear, clear_len, &bit)
+                                                   : s.strip_suffix_clear(a, clear, clear_len, &bit))
+                         : (base == "strip_prefix" ? s.strip_prefix(a, b, &bit) : s.strip_suffix(a, b, &bit));
         c.output(bit);          // first output: 1 iff the pattern was stripped
         s.emit(r);
     } else if (base == "find" || base == "rfind") {
@@ -801,29 +1039,56 @@ int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t 
     } else if (base == "strip" || base == "trim") {
         s.emit(s.trim_start(s.trim_end(a)));
     } else if (is_replace) {
-        // replace_clear: clear = from || to (two halves of equal length m)
-        // replace:       b = encrypted from || to (capacity 2m, no padding inside either half)
+        // replace_clear[:F:C]  clear = from (F bytes; default: half) || to,   output capacity C (default a_cap)
+        // replace[:F:C]        b = encrypted from (capacity F; default: half) || to
+        //   without parameters: equal lengths, encrypted operands fill their capacity, rewritten in place;
+        //   with parameters: any lengths, encrypted operands may be zero padded (hidden lengths)
+        if (!op_params.empty() && op_params.size() != 2) return fail("replace takes two parameters: pattern capacity and output capacity");
+        const bool general = !op_params.empty();
+        const uint32_t out_cap = general ? op_params[1] : a_cap;
+        if (out_cap == 0) return fail("output capacity must be > 0");
         if (is_clear) {
-            if (clear_len % 2) return fail("replace_clear expects `from` and `to` of equal length, concatenated");
-            const uint32_t m = clear_len / 2;
-            if (m == 0 || m > a_cap) { s.emit(a); }
+            if (!general && clear_len % 2) return fail("replace_clear expects `from` and `to` of equal length, concatenated");
+            const uint32_t m = general ? op_params[0] : clear_len / 2;
+            if (m > clear_len) return fail("replace_clear: pattern length beyond the clear buffer");
+            const uint32_t t = clear_len - m;
+            const uint8_t* to = clear + m;
+            if (m == 0) s.emit(general ? s.replace_empty_pattern(a, to, t, out_cap) : a);
+            else if (m > a_cap) s.emit(s.fit(a, out_cap));
             else {
                 std::vector<uint32_t> match = s.window_matches_clear(a, clear, m, a_cap - m + 1);
-                std::vector<uint32_t> sel = s.select_non_overlapping(match, m, StrOps::has_border(clear, m));
-                s.emit(s.replace_from_sel(a, sel, m, clear + m, nullptr));
+                StrOps::Occurrences oc = s.occurrences(match, m, a_cap, StrOps::has_border(clear, m), nullptr);
+                s.emit(m == t && out_cap == a_cap ? s.replace_in_place(a, oc, m, to, nullptr)
+                                                  : s.replace_general(a, oc, to, t, nullptr, out_cap));
             }
         } else {
-            if (b_cap % 2) return fail("replace expects `from` and `to` of equal capacity, concatenated");
-            const uint32_t m = b_cap / 2;
-            if (m > a_cap) { s.emit(a); }
-            else {
-                Str from, to;
-                from.cap = to.cap = m;
-                from.ch.assign(b.ch.begin(), b.ch.begin() + m);
-                to.ch.assign(b.ch.begin() + m, b.ch.end());
-                std::vector<uint32_t> match = s.window_matches(a, from, a_cap - m + 1, false);
-                std::vector<uint32_t> sel = s.select_non_overlapping(match, m, true);
-                s.emit(s.replace_from_sel(a, sel, m, nullptr, &to));
+            if (!general && b_cap % 2) return fail("replace expects `from` and `to` of equal capacity, concatenated");
+            const uint32_t m = general ? op_params[0] : b_cap / 2;
+            if (m == 0 || m > b_cap) return fail("replace: pattern capacity must be in 1..b_cap");
+            Str from, to;
+            from.cap = m;
+            to.cap = b_cap - m;
+            from.ch.assign(b.ch.begin(), b.ch.begin() + m);
+            to.ch.assign(b.ch.begin() + m, b.ch.end());
+            if (!general) {
+                if (m > a_cap) { s.emit(a); }
+                else {
+                    std::vector<uint32_t> match = s.window_matches(a, from, a_cap - m + 1, false);
+                    StrOps::Occurrences oc = s.occurrences(match, m, a_cap, true, nullptr);
+                    s.emit(s.replace_in_place(a, oc, m, nullptr, &to));
+                }
+            } else {
+                // padded pattern: its zero tail matches anything; an occurrence runs over from[j] != 0 only.
+                // A pattern that decrypts to the empty string selects nothing (nzf[0] = 0).
+                std::vector<uint32_t> nzf;
+                for (uint32_t j = 0; j < m; j++) nzf.push_back(s.not_bit(s.char_is_zero(from.ch[j])));
+                std::vector<uint32_t> match = s.window_matches(a, from, a_cap, true);
+                for (uint32_t o = 0; o < match.size(); o++) {
+                    StrOps::Scope sc(c, s.owner_for(o, (uint32_t)match.size()));
+                    match[o] = s.and_bits(match[o], nzf[0]);
+                }
+                StrOps::Occurrences oc = s.occurrences(match, m, a_cap, true, &nzf);
+                s.emit(s.replace_general(a, oc, nullptr, 0, to.cap ? &to : nullptr, out_cap));
             }
         }
     } else {

@@ -121,6 +121,7 @@ EXPORTS = [
     "fhe_str_trim_start", "fhe_str_trim_end", "fhe_str_strip", "fhe_str_replace", "fhe_str_replace_clear",
     "fhe_plan_lut_count", "fhe_plan_export_lut", "fhe_engine_set_stream", "fhe_engine_reset_stream",
     "fhe_str_len", "fhe_str_is_empty", "fhe_str_strip_prefix_clear", "fhe_str_strip_suffix_clear",
+    "fhe_str_strip_prefix", "fhe_str_strip_suffix", "fhe_str_replace_general", "fhe_str_replace_clear_general",
 ] + [f"fhe_str_{n}{s}" for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find", "rfind", "eq_ignore_case", "lt", "le", "gt", "ge", "concat")
      for s in ("", "_clear")] + ["fhe_str_repeat_clear"]
 
@@ -214,6 +215,10 @@ def lib() -> C.CDLL:
     sig("fhe_str_strip_prefix_clear", vp, vp, u32, vp, u32, vp)
     sig("fhe_str_strip_suffix_clear", vp, vp, u32, vp, u32, vp)
     sig("fhe_str_repeat_clear", vp, vp, u32, u32, vp)
+    sig("fhe_str_strip_prefix", vp, vp, u32, vp, u32, vp)
+    sig("fhe_str_strip_suffix", vp, vp, u32, vp, u32, vp)
+    sig("fhe_str_replace_general", vp, vp, u32, vp, u32, vp, u32, u32, vp)
+    sig("fhe_str_replace_clear_general", vp, vp, u32, vp, u32, vp, u32, u32, vp)
     for n in ("eq", "ne", "starts_with", "ends_with", "contains", "find", "rfind", "eq_ignore_case", "lt", "le", "gt", "ge", "concat"):
         sig(f"fhe_str_{n}", vp, vp, u32, vp, u32, vp)
         sig(f"fhe_str_{n}_clear", vp, vp, u32, vp, u32, vp)
@@ -694,15 +699,20 @@ class FheStringOps:
         _check(lib().fhe_str_is_empty(self.engine.handle, _ptr(a), a_cap, _ptr(out)))
         return out[0]
 
-    def _strip_affix(self, op, a, pat: bytes):
+    def _strip_affix(self, op, a, pat):
+        """pat: clear bytes, or an encrypted (zero padded) pattern."""
         a, a_cap = self._cap(a)
         out = np.zeros((1 + a.shape[0], self.engine.params.big_size), dtype=np.uint64)
-        buf = (C.c_uint8 * max(1, len(pat)))(*pat)
-        _check(getattr(lib(), f"fhe_str_{op}_clear")(self.engine.handle, _ptr(a), a_cap, buf, len(pat), _ptr(out)))
+        if isinstance(pat, (bytes, bytearray)):
+            buf = (C.c_uint8 * max(1, len(pat)))(*pat)
+            _check(getattr(lib(), f"fhe_str_{op}_clear")(self.engine.handle, _ptr(a), a_cap, buf, len(pat), _ptr(out)))
+        else:
+            pat, p_cap = self._cap(pat)
+            _check(getattr(lib(), f"fhe_str_{op}")(self.engine.handle, _ptr(a), a_cap, _ptr(pat), p_cap, _ptr(out)))
         return out[0], out[1:]
 
-    def strip_prefix(self, a, pat: bytes): return self._strip_affix("strip_prefix", a, pat)
-    def strip_suffix(self, a, pat: bytes): return self._strip_affix("strip_suffix", a, pat)
+    def strip_prefix(self, a, pat): return self._strip_affix("strip_prefix", a, pat)
+    def strip_suffix(self, a, pat): return self._strip_affix("strip_suffix", a, pat)
 
     def _unary(self, op, a):
         a, a_cap = self._cap(a)
@@ -714,23 +724,41 @@ class FheStringOps:
     def trim_end(self, a): return self._unary("trim_end", a)
     def strip(self, a): return self._unary("strip", a)
 
-    def replace(self, a, frm, to):
-        """Equal-length replace; frm/to both bytes (clear) or both encrypted (same capacity, unpadded)."""
+    def replace(self, a, frm, to, out_cap: int | None = None):
+        """Replace every leftmost non-overlapping occurrence of frm by to (bytes.replace).  frm / to: both
+        clear bytes, or both encrypted strings.  out_cap=None: the equal-length in-place form (encrypted
+        operands unpadded).  With out_cap: any lengths, encrypted operands may be zero padded, the result
+        has out_cap characters."""
         a, a_cap = self._cap(a)
-        out = np.zeros_like(a)
-        if isinstance(frm, (bytes, bytearray)):
-            if len(frm) != len(to):
-                raise FheError("replace: `from` and `to` must have the same length")
+        big = self.engine.params.big_size
+        clear = isinstance(frm, (bytes, bytearray))
+        if out_cap is None:
+            out = np.zeros_like(a)
+            if clear:
+                if len(frm) != len(to):
+                    raise FheError("replace: `from` and `to` of different lengths need an output capacity (out_cap)")
+                fb = (C.c_uint8 * max(1, len(frm)))(*frm)
+                tb = (C.c_uint8 * max(1, len(to)))(*to)
+                _check(lib().fhe_str_replace_clear(self.engine.handle, _ptr(a), a_cap, fb, tb, len(frm), _ptr(out)))
+            else:
+                frm, f_cap = self._cap(frm)
+                to, t_cap = self._cap(to)
+                if f_cap != t_cap:
+                    raise FheError("replace: `from` and `to` of different capacities need an output capacity (out_cap)")
+                both = np.concatenate([frm, to])
+                _check(lib().fhe_str_replace(self.engine.handle, _ptr(a), a_cap, _ptr(both), f_cap, _ptr(out)))
+            return out
+        out = np.zeros((out_cap * self.bpc, big), dtype=np.uint64)
+        if clear:
             fb = (C.c_uint8 * max(1, len(frm)))(*frm)
             tb = (C.c_uint8 * max(1, len(to)))(*to)
-            _check(lib().fhe_str_replace_clear(self.engine.handle, _ptr(a), a_cap, fb, tb, len(frm), _ptr(out)))
+            _check(lib().fhe_str_replace_clear_general(self.engine.handle, _ptr(a), a_cap, fb, len(frm), tb, len(to),
+                                                       out_cap, _ptr(out)))
         else:
             frm, f_cap = self._cap(frm)
             to, t_cap = self._cap(to)
-            if f_cap != t_cap:
-                raise FheError("replace: `from` and `to` must have the same capacity")
-            both = np.concatenate([frm, to])
-            _check(lib().fhe_str_replace(self.engine.handle, _ptr(a), a_cap, _ptr(both), f_cap, _ptr(out)))
+            _check(lib().fhe_str_replace_general(self.engine.handle, _ptr(a), a_cap, _ptr(frm), f_cap,
+                                                 _ptr(to) if t_cap else None, t_cap, out_cap, _ptr(out)))
         return out
 
     def concat(self, a, b):

@@ -226,9 +226,23 @@ int fhe_str_repeat_clear(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uin
 int fhe_str_trim_start(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
 int fhe_str_trim_end(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
 int fhe_str_strip(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
-/* replace every leftmost non-overlapping occurrence of `from` by `to` (equal lengths, so the string
- * keeps its length).  Encrypted form: from_to = pat_cap chars of `from` then pat_cap chars of `to`,
- * neither padded.  Plan op names: "replace" (b_cap = 2*pat_cap) / "replace_clear" (clear = from||to). */
+/* replace every leftmost non-overlapping occurrence of `from` by `to` (Rust's str::replace / Python's
+ * bytes.replace).
+ * Equal-length forms (the string keeps its shape and is rewritten in place): from_to = pat_cap chars of
+ * `from` then pat_cap chars of `to`, neither padded.  Plan op names: "replace" (b_cap = 2*pat_cap) /
+ * "replace_clear" (clear = from||to).
+ * General forms: any lengths, the result has `out_cap` characters (longer results are cut, so give
+ * a_cap + max(0, |to| - |from|) * (a_cap / |from|) to be safe).  Encrypted `from` / `to` may be zero
+ * padded (hidden lengths; to_cap == 0 deletes); an encrypted `from` that decrypts to the empty string
+ * replaces nothing, a clear empty `from` inserts `to` before every character and at the end like Rust and
+ * Python do.  Plan op names "replace:<from_cap>:<out_cap>" (b = from || to) and
+ * "replace_clear:<from_len>:<out_cap>" (clear = from || to). */
+int fhe_str_replace_general(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const uint64_t *from,
+                            uint32_t from_cap, const uint64_t *to, uint32_t to_cap, uint32_t out_cap,
+                            uint64_t *out);
+int fhe_str_replace_clear_general(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const uint8_t *from,
+                                  uint32_t from_len, const uint8_t *to, uint32_t to_len, uint32_t out_cap,
+                                  uint64_t *out);
 int fhe_str_replace(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const uint64_t *from_to,
                     uint32_t pat_cap, uint64_t *out);
 int fhe_str_replace_clear(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const uint8_t *from,
@@ -242,6 +256,11 @@ int fhe_str_strip_prefix_clear(fhe_engine *eng, const uint64_t *a, uint32_t a_ca
                                uint32_t pat_len, uint64_t *out);
 int fhe_str_strip_suffix_clear(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const uint8_t *pat,
                                uint32_t pat_len, uint64_t *out);
+/* the same with an encrypted, zero padded pattern (hidden length) */
+int fhe_str_strip_prefix(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const uint64_t *pat,
+                         uint32_t pat_cap, uint64_t *out);
+int fhe_str_strip_suffix(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const uint64_t *pat,
+                         uint32_t pat_cap, uint64_t *out);
 int fhe_str_to_upper(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
 int fhe_str_to_lower(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
 

@@ -166,29 +166,43 @@ def _free_port():
         return s.getsockname()[1]
 
 
+SHARDED_CASES = [   # (op, a_cap, b_cap, clear, a, b)
+    ("contains", 8, 4, None, b"abcabd", b"abd"),
+    ("eq", 7, 7, None, b"abcdefg", b"abcdefg"),          # 7 characters over 4 ranks: uneven slices
+    ("eq", 7, 7, None, b"abcdefg", b"abcdefh"),
+    ("find", 7, 3, None, b"xxabdab", b"abd"),            # prefix scan: ownership decided by the leveliser
+    ("to_lower", 5, 0, None, b"HeLLo", None),            # every output block is gathered
+    ("replace_clear:2:9", 6, 0, b"bcXYZ", b"abcabc", None),
+]
+
+
 def _gloo_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     for p in (ROOT, os.path.join(ROOT, "fhe-string-bounty_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     import torch.distributed as dist
+    from fhestr.distributed import ShardedPlanRunner
+    from plan_oracle import OracleBackend
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ks = keyset(O.TOY_K1)
-        plan = _plan("contains", 8, 4, world=world)
-        inputs = np.concatenate([_enc(ks, b"abcabd", 8), _enc(ks, b"abd", 4)])  # deterministic per seed
-        out = run_with_oracle(plan, inputs, ks.sk, rank, world)
-        ret[rank] = int(ks.ck.decrypt_many(out)[0])
+        out = []
+        for op, a_cap, b_cap, clear, a, b in SHARDED_CASES:
+            plan = _plan(op, a_cap, b_cap, clear, world=world)
+            inputs = _enc(ks, a, a_cap)                   # deterministic per seed: same ciphertexts on every rank
+            if b is not None:
+                inputs = np.concatenate([inputs, _enc(ks, b, b_cap)])
+            runner = ShardedPlanRunner(plan, rank, world, OracleBackend(plan, ks.sk))
+            res = ks.ck.decrypt_many(runner.run(inputs)).tolist()
+            out.append((res, runner.gathered_lwes, runner.collectives))
+        ret[rank] = out
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_runner_world2_gloo(toy_k1):
-    """N>1 path on CPU: two ranks each compute half of every level, all-gather, agree on the result
-    and agree with the single-rank run."""
+def _run_sharded(world):
     import torch.multiprocessing as mp
-    world = 2
-    single = _run(toy_k1, "contains", b"abcabd", b"abd")[0]
     mgr = mp.Manager()
     ret = mgr.dict()
     port = _free_port()
@@ -197,9 +211,40 @@ def test_sharded_runner_world2_gloo(toy_k1):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(240)
         assert p.exitcode == 0
-    assert dict(ret) == {0: single, 1: single} and single == 1
+    return dict(ret)
+
+
+def _single_rank_results(ks):
+    out = []
+    for op, a_cap, b_cap, clear, a, b in SHARDED_CASES:
+        plan = _plan(op, a_cap, b_cap, clear)
+        inputs = _enc(ks, a, a_cap)
+        if b is not None:
+            inputs = np.concatenate([inputs, _enc(ks, b, b_cap)])
+        out.append(ks.ck.decrypt_many(run_with_oracle(plan, inputs, ks.sk)).tolist())
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_runner_gloo(toy_k1, world):
+    """N>1 path on CPU (gloo): every rank runs only the jobs it owns, exported ciphertexts are all-gathered,
+    all ranks agree with each other and with the single-rank run.  World 4 splits 7- and 5-character
+    strings unevenly (some ranks own one character, some two; some own nothing at the small levels)."""
+    import fhestr
+    P = to_fhestr_params(O.TOY_K1)
+    single = _single_rank_results(toy_k1)
+    assert single[0] == [1] and single[1] == [1] and single[2] == [0]
+    assert fhestr.blocks_to_string(P, single[4]) == b"hello"
+    assert fhestr.blocks_to_string(P, single[5]) == b"aXYZaXYZ"
+    ret = _run_sharded(world)
+    assert sorted(ret) == list(range(world))
+    for r in range(world):
+        assert [res for res, _, _ in ret[r]] == single, f"rank {r}"
+    # eq: one block per rank gathered after the local reduction, then the final bit
+    eq_gathered, eq_collectives = ret[0][1][1], ret[0][1][2]
+    assert eq_gathered == 2 * world and eq_collectives == 2
 
 
 def test_config1_eq_8_chars_p22_cpu_reference_path(p22):
@@ -244,3 +289,146 @@ def test_concat_repeat_offline_plan_vs_python(toy_k1, a, b):
         plan = _plan("repeat_clear", 4, 0, bytes([3]))
         got = toy_k1.ck.decrypt_many(run_with_oracle(plan, _enc(toy_k1, a, 4), toy_k1.sk))
         assert fhestr.blocks_to_string(P, got) == a * 3
+
+
+# ---- general replace (|from| != |to|), clear and encrypted (padded) patterns ---------------------
+GENERAL_REPLACE = [
+    (b"abcabc", b"bc", b"X"),          # shrink
+    (b"abcabc", b"b", b"XYZ"),         # growth
+    (b"aaaa", b"aa", b"b"),            # adjacent occurrences
+    (b"aaa", b"aa", b"xyz"),           # overlapping candidates: leftmost wins
+    (b"hello", b"l", b""),             # deletion
+    (b"hello", b"zz", b"y"),           # no occurrence
+    (b"abab", b"ab", b"ab"),           # same length through the general path
+    (b"", b"a", b"bc"),                # empty string
+    (b"abc", b"abc", b"z"),            # whole string
+    (b"abcabc", b"abc", b"abcd"),      # result fills the output capacity
+]
+
+
+@pytest.mark.parametrize("s,frm,to", GENERAL_REPLACE)
+def test_general_replace_clear_offline_plan_vs_python(toy_k1, s, frm, to):
+    import fhestr
+    P = to_fhestr_params(O.TOY_K1)
+    want = s.replace(frm, to)
+    out_cap = max(len(want), 1)
+    plan = _plan(f"replace_clear:{len(frm)}:{out_cap}", 6, 0, frm + to)
+    got = toy_k1.ck.decrypt_many(run_with_oracle(plan, _enc(toy_k1, s, 6), toy_k1.sk))
+    assert fhestr.blocks_to_string(P, got) == want
+    assert plan.info()["n_outputs"] == out_cap * 4
+
+
+@pytest.mark.parametrize("s,frm,to", GENERAL_REPLACE[:7])
+def test_general_replace_encrypted_padded_offline_plan_vs_python(toy_k1, s, frm, to):
+    """Encrypted `from` / `to` with hidden lengths (capacity 3, zero padded)."""
+    import fhestr
+    P = to_fhestr_params(O.TOY_K1)
+    want = s.replace(frm, to)
+    out_cap = 10
+    plan = _plan(f"replace:3:{out_cap}", 6, 6)
+    inputs = np.concatenate([_enc(toy_k1, s, 6), _enc(toy_k1, frm, 3), _enc(toy_k1, to, 3)])
+    got = toy_k1.ck.decrypt_many(run_with_oracle(plan, inputs, toy_k1.sk))
+    assert fhestr.blocks_to_string(P, got) == want
+
+
+def test_replace_empty_patterns(toy_k1):
+    """Clear empty `from`: `to` before every character and at the end (bytes.replace(b"", to)); an
+    encrypted `from` that decrypts to the empty string replaces nothing (documented in fhestr.h)."""
+    import fhestr
+    P = to_fhestr_params(O.TOY_K1)
+    for s in (b"ab", b"", b"abc"):
+        want = s.replace(b"", b"-")
+        plan = _plan("replace_clear:0:8", 3, 0, b"-")
+        got = toy_k1.ck.decrypt_many(run_with_oracle(plan, _enc(toy_k1, s, 3), toy_k1.sk))
+        assert fhestr.blocks_to_string(P, got) == want
+    plan = _plan("replace:2:6", 4, 4)
+    inputs = np.concatenate([_enc(toy_k1, b"abab", 4), _enc(toy_k1, b"", 2), _enc(toy_k1, b"zz", 2)])
+    got = toy_k1.ck.decrypt_many(run_with_oracle(plan, inputs, toy_k1.sk))
+    assert fhestr.blocks_to_string(P, got) == b"abab"
+
+
+@pytest.mark.parametrize("s,pat", [(b"abcabc", b"abc"), (b"abcabc", b"bc"), (b"abc", b""), (b"", b""), (b"ab", b"abc"),
+                                   (b"aaa", b"a"), (b"abcabc", b"abcabc")])
+def test_strip_prefix_suffix_encrypted_pattern(toy_k1, s, pat):
+    """strip_prefix / strip_suffix with an encrypted, zero padded pattern == Rust's strip_prefix /
+    Python's removeprefix (+ the "was there" bit)."""
+    import fhestr
+    P = to_fhestr_params(O.TOY_K1)
+    for op, had, want in (("strip_prefix", s.startswith(pat), s[len(pat):] if s.startswith(pat) else s),
+                          ("strip_suffix", s.endswith(pat), s[:len(s) - len(pat)] if s.endswith(pat) else s)):
+        plan = _plan(op, 6, 6)
+        inputs = np.concatenate([_enc(toy_k1, s, 6), _enc(toy_k1, pat, 6)])
+        out = toy_k1.ck.decrypt_many(run_with_oracle(plan, inputs, toy_k1.sk))
+        assert out[0] == int(had), op
+        assert fhestr.blocks_to_string(P, out[1:]) == want, op
+
+
+# ---- value ranges and noise are checked when a plan is built -------------------------------------
+def test_plan_rejects_negative_and_noisy_pbs_inputs():
+    import fhestr
+    P = to_fhestr_params(O.PARAM_MESSAGE_2_CARRY_2_KS_PBS)
+    plan = fhestr.Plan(None, params=P)
+    a, b = plan.input(3), plan.input(3)
+    ident = plan.lut(lambda x: x)
+    diff = plan.lin([(a, 1), (b, -1)])
+    with pytest.raises(fhestr.FheError, match="negative"):
+        plan.pbs(diff, ident)                         # a - b may wrap into the padding bit
+    plan.pbs(plan.lin([(a, 1), (b, -1)], 3), ident)   # the reference's correcting constant: fine
+    plan.pbs(diff, plan.lut(lambda x: int(x == 0)), signed=True)   # declared use of the padding bit
+    with pytest.raises(fhestr.FheError, match="overflows"):
+        plan.pbs(plan.lin([(a, 4), (b, 2)]), ident)   # 12 + 6 > 15
+    m = fhestr.noise_model(P)
+    assert 25 <= m["budget"] < 400 and m["log2_pfail_at_budget"] < -39
+    narrow = plan.input(0)
+    with pytest.raises(fhestr.FheError, match="noise"):
+        plan.pbs(plan.lin([(narrow, 15)]), ident)     # 225 nominal variances
+    plan.set_noise_budget(0)                          # unchecked, like the reference's unchecked_* ops
+    plan.pbs(plan.lin([(narrow, 15)]), ident)
+
+
+def test_noise_model_matches_the_reference_parameter_sets():
+    """The model's worst-case failure probability at the reference's own noise bound (norm2 =
+    max_noise_level) is what the parameter sets are generated for: ~2^-40
+    (docs/getting_started/security_and_cryptography.md:96)."""
+    import fhestr
+    for P in (fhestr.PARAM_MESSAGE_2_CARRY_2_KS_PBS, fhestr.PARAM_MESSAGE_4_CARRY_4_KS_PBS):
+        m = fhestr.noise_model(P)
+        std = (m["v_ks"] + m["v_ms"]) ** 0.5
+        assert 6.8 < m["half_box"] / std < 8.5, P.name
+        assert -55 < m["log2_pfail_at_budget"] < -39, (P.name, m)
+
+
+# ---- sharded plans: owners, exports, what travels ------------------------------------------------
+def test_sharded_eq_reduces_locally_and_gathers_one_block_per_rank():
+    """SURVEY 8(e): FheString::eq on 256 chars over 8 ranks -- every rank compares its 32 characters and
+    reduces them to ONE block; two all-gathers of one ciphertext per rank (the per-rank results, then the
+    final bit) instead of every level's whole output."""
+    import fhestr
+    P = to_fhestr_params(O.PARAM_MESSAGE_2_CARRY_2_KS_PBS)
+    plan = fhestr.Plan.string_op(None, "eq", 256, 256, world=8, params=P)
+    info = plan.info()
+    levels = [plan.level_info(l) for l in range(info["n_levels"])]
+    assert info["n_levels"] == 4
+    assert [lv["e_max"] for lv in levels] == [0, 0, 1, 1]
+    gathered = sum(lv["e_max"] * 8 for lv in levels)
+    assert gathered == 16 and gathered * P.big_size * 8 < 1.2e6      # SURVEY's 1.18 MB figure is the ceiling
+    assert plan.noise_info()["gathered_lwes"] == 16
+    for r in range(8):          # level 1: 64 packed compares per rank, all private
+        ri = plan.level_rank_info(0, r)
+        assert ri["job_hi"] - ri["job_lo"] == 64 and ri["n_export"] == 0
+    single = fhestr.Plan.string_op(None, "eq", 256, 256, world=1, params=P).info()
+    assert info["n_pbs"] <= single["n_pbs"] + 16      # rank-aligned reduction groups: a few more small PBS
+
+
+def test_sharded_contains_keeps_offsets_on_their_rank():
+    import fhestr
+    P = to_fhestr_params(O.PARAM_MESSAGE_2_CARRY_2_KS_PBS)
+    plan = fhestr.Plan.string_op(None, "contains", 256, 16, world=8, params=P)
+    info = plan.info()
+    levels = [plan.level_info(l) for l in range(info["n_levels"])]
+    gathered = sum(lv["e_max"] * 8 for lv in levels)
+    # the pattern's 16 zero-flags are shared by every offset (computed once, exported), then one block per rank
+    assert gathered * P.big_size * 8 < 4e6, gathered
+    biggest = max(range(len(levels)), key=lambda l: levels[l]["jobs"])
+    sizes = [plan.level_rank_info(biggest, r)["job_hi"] - plan.level_rank_info(biggest, r)["job_lo"] for r in range(8)]
+    assert max(sizes) <= 1.35 * min(sizes)          # balanced (the last offsets run past the capacity: fewer compares)
