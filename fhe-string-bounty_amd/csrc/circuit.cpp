@@ -49,7 +49,7 @@ uint32_t Circuit::lin(const std::vector<Term>& terms, int64_t cst, int64_t degre
     // range than its flattened leaves would suggest)
     int64_t lo = cst, hi = cst;
     for (const Term& t : terms) {
-        if (t.node >= nodes_.size()) { error_ = "lin: bad node id"; return 0; }
+        if (t.node >= nodes_.size()) { set_error("lin: bad node id"); return 0; }
         const Node& s = nodes_[t.node];
         if (t.coeff >= 0) { lo += (int64_t)t.coeff * s.vmin; hi += (int64_t)t.coeff * s.vmax; }
         else              { lo += (int64_t)t.coeff * s.vmax; hi += (int64_t)t.coeff * s.vmin; }
@@ -62,7 +62,7 @@ uint32_t Circuit::lin(const std::vector<Term>& terms, int64_t cst, int64_t degre
     double noise = 0.0;
     for (auto& kv : acc) {
         if (kv.second == 0) continue;
-        if (kv.second > INT32_MAX || kv.second < INT32_MIN) { error_ = "lin: coefficient overflow"; return 0; }
+        if (kv.second > INT32_MAX || kv.second < INT32_MIN) { set_error("lin: coefficient overflow"); return 0; }
         n.terms.push_back({kv.first, (int32_t)kv.second});
         lvl = std::max(lvl, nodes_[kv.first].level);
         noise += (double)kv.second * (double)kv.second * nodes_[kv.first].noise;   // add.rs:523, on variances
@@ -93,7 +93,7 @@ int Circuit::owner_of(uint32_t id) const {
 uint32_t Circuit::lut(const std::vector<uint64_t>& table) {
     auto it = lut_cache_.find(table);
     if (it != lut_cache_.end()) return it->second;
-    if (table.size() != total_modulus()) { error_ = "lut: table size must be msg_mod*carry_mod"; return 0; }
+    if (table.size() != total_modulus()) { set_error("lut: table size must be msg_mod*carry_mod"); return 0; }
     std::vector<uint64_t> acc;
     fill_accumulator(p_, table.data(), acc);
     const uint32_t id = (uint32_t)lut_accs_.size();
@@ -104,30 +104,30 @@ uint32_t Circuit::lut(const std::vector<uint64_t>& table) {
 }
 
 uint32_t Circuit::pbs(uint32_t id, uint32_t lut_id, bool signed_input) {
-    if (id >= nodes_.size()) { error_ = "pbs: bad node id"; return 0; }
-    if (lut_id >= lut_tables_.size()) { error_ = "pbs: LUT was not created through this plan"; return 0; }
+    if (id >= nodes_.size()) { set_error("pbs: bad node id"); return 0; }
+    if (lut_id >= lut_tables_.size()) { set_error("pbs: LUT was not created through this plan"); return 0; }
     const std::vector<uint64_t>* table = &lut_tables_[lut_id];
     uint32_t src = id;
     if (nodes_[id].kind != Node::LIN) src = lin({{id, 1}});
     const Node& s = nodes_[src];
     const int64_t T = (int64_t)total_modulus();
     if (s.vmax >= T) {
-        error_ = "pbs: input degree " + std::to_string(s.vmax) + " overflows the message+carry space";
+        set_error("pbs: input degree " + std::to_string(s.vmax) + " overflows the message+carry space");
         return 0;
     }
     if (s.vmin < 0 && !signed_input) {
-        error_ = "pbs: input may be negative (down to " + std::to_string(s.vmin) + "): it would wrap into the padding bit "
-                 "and be read through the table's negacyclic extension; add a constant, or declare a signed input";
+        set_error("pbs: input may be negative (down to " + std::to_string(s.vmin) + "): it would wrap into the padding bit "
+                 "and be read through the table's negacyclic extension; add a constant, or declare a signed input");
         return 0;
     }
     if (s.vmin <= -T) {
-        error_ = "pbs: signed input " + std::to_string(s.vmin) + " leaves the padding bit's range";
+        set_error("pbs: signed input " + std::to_string(s.vmin) + " leaves the padding bit's range");
         return 0;
     }
     if (s.terms.empty()) {
         // trivial ciphertext: clear table lookup (shortint/server_key/mod.rs:763-781)
         const int64_t v = s.cst;
-        if (v < 0 || v >= T) { error_ = "pbs: trivial value out of range"; return 0; }
+        if (v < 0 || v >= T) { set_error("pbs: trivial value out of range"); return 0; }
         return trivial((int64_t)(*table)[(size_t)v]);
     }
     // MaxNoiseLevel::validate (shortint/ciphertext/mod.rs:28-55), on variances
@@ -136,7 +136,7 @@ uint32_t Circuit::pbs(uint32_t id, uint32_t lut_id, bool signed_input) {
         char buf[200];
         snprintf(buf, sizeof buf, "pbs: input noise %.1f nominal variances exceeds this parameter set's budget of %.1f",
                  s.noise, noise_budget_);
-        error_ = buf;
+        set_error(buf);
         return 0;
     }
     Node n;

@@ -152,6 +152,7 @@ public:
     ~Circuit();
 
 private:
+    void set_error(std::string e) { if (error_.empty()) error_ = std::move(e); }   // the first error is the cause
     void flatten(uint32_t node, int64_t mult, std::map<uint32_t, int64_t>& acc, int64_t& cst) const;
     void build_csr(Level& lv, const std::vector<uint32_t>& lin_nodes);
 

@@ -123,10 +123,22 @@ public:
     uint32_t all_true(const std::vector<uint32_t>& bits) { return reduce_bits(bits, true); }
     uint32_t any_true(const std::vector<uint32_t>& bits) { return reduce_bits(bits, false); }
 
+    // message_extract (shortint/server_key/mod.rs: x -> x % msg_mod) of a block that carries more than
+    // nominal noise (a sum of ciphertexts): back to NoiseLevel::NOMINAL for one PBS
+    std::map<uint32_t, uint32_t> fresh_memo;
+    uint32_t fresh(uint32_t block) {
+        if (c.node(block).noise <= 1.0) return block;
+        auto it = fresh_memo.find(block);
+        if (it != fresh_memo.end()) return it->second;
+        const uint32_t mm = M;
+        return fresh_memo[block] = c.pbs(block, c.lut_fn([mm](uint64_t x) { return x % mm; }));
+    }
     // ---- block-level comparisons ----
     // bivariate LUT on lhs*M + rhs (bivariate_pbs.rs:71-96,167-182)
     uint32_t block_eq(uint32_t a, uint32_t b, bool want_equal) {
         const uint32_t m = M;
+        if ((double)M * M * c.node(a).noise + c.node(b).noise > budget()) a = fresh(a);     // noisy operands
+        if ((double)M * M * c.node(a).noise + c.node(b).noise > budget()) b = fresh(b);
         const uint32_t l = c.lut_fn([m, want_equal](uint64_t x) {
             const uint64_t lhs = (x / m) % m, rhs = (x % m) % m;
             return (uint64_t)((lhs == rhs) == want_equal);
@@ -851,7 +863,10 @@ public:
         std::vector<uint32_t> signs;   // most significant first
         const uint32_t mm = M;
         for (uint32_t i = 0; i < n; i++) {
-            if (b && packed_compare && bpc % 2 == 0 && i < a.cap && i < b->cap) {
+            bool packed = b && packed_compare && bpc % 2 == 0 && i < a.cap && i < b->cap;
+            for (uint32_t k = 0; packed && k + 1 < bpc; k += 2)
+                packed = packed_pair_fits(a.ch[i][k], a.ch[i][k + 1], b->ch[i][k], b->ch[i][k + 1]);
+            if (packed) {
                 // sign of a packed block pair in one PBS: the sign function is odd, hence negacyclic for
                 // free -- f(0) = 0, f(1..T-1) = 1 gives -1 on the negative (padding-bit) side; +1 maps
                 // {-1, 0, 1} onto the {0, 1, 2} encoding

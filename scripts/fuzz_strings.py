@@ -55,7 +55,7 @@ for case in range(N_CASES):
     ea, eb = enc(a, cap), enc(b, b_cap)
     op = str(rng.choice(["eq", "ne", "lt", "le", "gt", "ge", "eqic", "starts", "ends", "contains", "find", "rfind",
                          "upper", "lower", "trim_start", "trim_end", "strip", "replace", "len", "is_empty",
-                         "strip_prefix", "strip_suffix", "concat", "repeat"]))
+                         "strip_prefix", "strip_suffix", "concat", "repeat", "replace_general"]))
     clear = bool(rng.random() < 0.5)
     rhs = b if clear else eb
     ctx = (op, a, b, cap, b_cap, clear)
@@ -99,6 +99,18 @@ for case in range(N_CASES):
         else:
             got = dec_str(ops.replace(ea, enc(b, len(b)), enc(to, len(b))))
         check(op, got, a.replace(b, to), ctx + (to,))
+    elif op == "replace_general":
+        # any lengths; clear operands (incl. the empty pattern) or encrypted zero padded ones
+        to = bytes(ALPHA[int(i)] for i in rng.integers(0, len(ALPHA), size=int(rng.integers(0, 4))))
+        if not clear and len(b) == 0:
+            continue        # an encrypted empty pattern replaces nothing by definition (fhestr.h)
+        want = a.replace(b, to)
+        out_cap = max(1, len(want) + int(rng.integers(0, 2)))
+        if clear:
+            got = dec_str(ops.replace(ea, b, to, out_cap=out_cap))
+        else:
+            got = dec_str(ops.replace(ea, eb, enc(to, max(1, len(to) + int(rng.integers(0, 2)))), out_cap=out_cap))
+        check(op, got, want, ctx + (to, out_cap))
     elif op == "len":
         check(op, digits_to_int(dec(ops.len(ea))), len(a), ctx)
     elif op == "is_empty":
@@ -109,7 +121,7 @@ for case in range(N_CASES):
         n = int(rng.integers(1, 4))
         check(op, dec_str(ops.repeat(ea, n)), a * n, ctx + (n,))
     elif op in ("strip_prefix", "strip_suffix"):
-        bit, out = getattr(ops, op)(ea, b)
+        bit, out = getattr(ops, op)(ea, rhs)          # clear or encrypted (padded) pattern
         had = a.startswith(b) if op == "strip_prefix" else a.endswith(b)
         want = (a[len(b):] if op == "strip_prefix" else a[:len(a) - len(b)]) if had else a
         check(op + ".bit", int(dec(bit)[0]), int(had), ctx)

@@ -294,3 +294,53 @@ def test_fuzz_string_ops_against_python():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_strings.py"), "400", "7"],
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+GENERAL_REPLACE = [(b"abcabc", b"bc", b"X"), (b"abcabc", b"b", b"XYZ"), (b"aaaa", b"aa", b"b"), (b"aaa", b"aa", b"xyz"),
+                   (b"hello", b"l", b""), (b"hello", b"zz", b"y"), (b"", b"a", b"bc"), (b"abcabc", b"abc", b"abcd")]
+
+
+@pytest.mark.parametrize("s,frm,to", GENERAL_REPLACE)
+def test_general_replace_gpu(toy_k1, s, frm, to):
+    """replace with |from| != |to| through the C ABI: clear operands, and encrypted zero padded ones
+    (hidden lengths), against bytes.replace incl. growth, shrink, deletion and overlapping candidates."""
+    import fhestr
+    ops = _ops(toy_k1)
+    P = gpu_engine(toy_k1).params
+    want = s.replace(frm, to)
+    es = _enc(toy_k1, s, 6)
+    out_cap = max(len(want), 1)
+    assert fhestr.blocks_to_string(P, _dec(toy_k1, ops.replace(es, frm, to, out_cap=out_cap))) == want
+    enc_out = ops.replace(es, _enc(toy_k1, frm, 3), _enc(toy_k1, to, 3), out_cap=10)
+    assert fhestr.blocks_to_string(P, _dec(toy_k1, enc_out)) == want
+
+
+def test_replace_empty_clear_pattern_and_padded_strip_gpu(toy_k1):
+    import fhestr
+    ops = _ops(toy_k1)
+    P = gpu_engine(toy_k1).params
+    es = _enc(toy_k1, b"ab", 3)
+    assert fhestr.blocks_to_string(P, _dec(toy_k1, ops.replace(es, b"", b"-", out_cap=8))) == b"ab".replace(b"", b"-")
+    s = b"abcabc"
+    es = _enc(toy_k1, s, 6)
+    for pat in (b"abc", b"bc", b"", b"abcabc", b"x"):
+        ep = _enc(toy_k1, pat, 6)
+        bit, rest = ops.strip_prefix(es, ep)
+        assert _dec(toy_k1, bit)[0] == int(s.startswith(pat))
+        assert fhestr.blocks_to_string(P, _dec(toy_k1, rest)) == (s[len(pat):] if s.startswith(pat) else s)
+        bit, rest = ops.strip_suffix(es, ep)
+        assert _dec(toy_k1, bit)[0] == int(s.endswith(pat))
+        assert fhestr.blocks_to_string(P, _dec(toy_k1, rest)) == (s[:len(s) - len(pat)] if s.endswith(pat) else s)
+
+
+def test_p22_general_replace_64_chars(p22):
+    """General replace on the real parameter set: growth and shrink on a 64-char string."""
+    import fhestr
+    ops = _ops(p22)
+    P = gpu_engine(p22).params
+    s = b"the cat and the hat sat on the mat; the end"
+    es = _enc(p22, s, 48)
+    for frm, to in ((b"the ", b"a "), (b"at", b"ouse")):
+        want = s.replace(frm, to)
+        got = fhestr.blocks_to_string(P, _dec(p22, ops.replace(es, frm, to, out_cap=64)))
+        assert got == want

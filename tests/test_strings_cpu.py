@@ -432,3 +432,17 @@ def test_sharded_contains_keeps_offsets_on_their_rank():
     biggest = max(range(len(levels)), key=lambda l: levels[l]["jobs"])
     sizes = [plan.level_rank_info(biggest, r)["job_hi"] - plan.level_rank_info(biggest, r)["job_lo"] for r in range(8)]
     assert max(sizes) <= 1.35 * min(sizes)          # balanced (the last offsets run past the capacity: fewer compares)
+
+
+def test_string_plans_stay_inside_the_noise_budget():
+    """Every FheString plan on the real parameter sets: the noisiest PBS input is within the budget (the
+    builder would have refused it otherwise) and its modelled failure probability is reported."""
+    import fhestr
+    for P, a_cap in ((fhestr.PARAM_MESSAGE_2_CARRY_2_KS_PBS, 64), (fhestr.PARAM_MESSAGE_4_CARRY_4_KS_PBS, 64)):
+        for op, b_cap, clear in (("eq", a_cap, None), ("contains", 8, None), ("find", 8, None), ("to_lower", 0, None),
+                                 ("strip", 0, None), ("replace_clear", 0, b"\xff\xfe\xfd\xfc" + b"\xff\xff\xff\xff"),
+                                 ("replace_clear:2:80", 0, b"ab\xff\xff\xff"), ("eq_ignore_case", a_cap, None), ("lt", a_cap, None)):
+            plan = fhestr.Plan.string_op(None, op, a_cap, b_cap, clear, params=P)
+            ni = plan.noise_info()
+            assert 0 < ni["max_pbs_input_noise"] <= ni["budget"], (P.name, op, ni)
+            assert ni["log2_pfail_worst"] < -38.5, (P.name, op, ni)
