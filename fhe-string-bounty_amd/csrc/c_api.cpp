@@ -61,10 +61,10 @@ int fhe_engine_load_keys(fhe_engine* eng, const uint64_t* bsk_std, const uint64_
     API_END
 }
 
-int fhe_engine_generate_keys(fhe_engine* eng, const uint64_t* glwe_sk, const uint64_t* small_sk, uint64_t seed,
+int fhe_engine_generate_keys(fhe_engine* eng, const uint64_t* glwe_sk, const uint64_t* small_sk, const uint8_t seed[32],
                              uint64_t* bsk_std_out, uint64_t* ksk_out) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(glwe_sk); CHECK_PTR(small_sk);
+    CHECK_PTR(eng); CHECK_PTR(glwe_sk); CHECK_PTR(small_sk); CHECK_PTR(seed);
     return eng->impl->generate_keys(glwe_sk, small_sk, seed, bsk_std_out, ksk_out);
     API_END
 }

@@ -2,10 +2,14 @@
 // generation.  CPU code by design: in the reference these are ClientKey operations that never run
 // on the evaluation path (shortint/engine/client_side.rs:13-128, shortint/client_key/mod.rs:281-337,
 // shortint/engine/server_side.rs:54-160) and SURVEY.md section 8(f) ranks device-side key generation
-// as a later row.  Randomness: xoshiro256** seeded through splitmix64 (the reference's AES-CTR
-// CSPRNG, concrete-csprng, is out of scope); noise follows the reference's Gaussian sampler
+// as a later row.  Randomness: ChaCha20 keystream under a 256-bit seed, one stream per purpose and key
+// row (det_math.h; stands in for the reference's AES-128-CTR concrete-csprng with forked generators);
+// noise follows the reference's Gaussian sampler
 // (core_crypto/commons/math/random/gaussian.rs:17-47, polar method on two signed 64-bit draws) --
 // both live in det_math.h, shared with the device-side key generation kernels.
+#include <errno.h>
+#include <sys/random.h>
+
 #include <cmath>
 #include <cstring>
 #include <thread>
@@ -18,12 +22,12 @@ namespace fhe {
 
 struct ClientKey {
     fhe_params_t p;
-    uint64_t seed;
+    Seed256 seed;
     std::vector<uint64_t> glwe_sk;    // k*N bits; also the big LWE key (client_side.rs:29)
     std::vector<uint64_t> small_sk;   // n bits
     Rng enc_rng;
 
-    ClientKey(const fhe_params_t& params, uint64_t seed_)
+    ClientKey(const fhe_params_t& params, const Seed256& seed_)
         : p(params), seed(seed_), glwe_sk((size_t)params.k * params.N), small_sk(params.n), enc_rng(seed_, 3) {
         fill_binary(glwe_sk, 1);
         fill_binary(small_sk, 2);
@@ -145,12 +149,33 @@ size_t fhe_params_bsk_len(const fhe_params_t* p) {
     return (size_t)fhe::n_ggsw(*p) * p->pbs_level * (p->k + 1) * (p->k + 1) * p->N;
 }
 
-int fhe_client_key_create(const fhe_params_t* params, uint64_t seed, fhe_client_key** out) {
+int fhe_random_seed(uint8_t seed[32]) {
+    if (!seed) return fhe::fail("null pointer: seed");
+    size_t got = 0;
+    while (got < 32) {                       // the kernel's CSPRNG (getrandom(2)); never blocks once initialised
+        const ssize_t r = getrandom(seed + got, 32 - got, 0);
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            return fhe::fail("getrandom failed: no entropy source");
+        }
+        got += (size_t)r;
+    }
+    return 0;
+}
+
+int fhe_chacha20_block(const uint8_t key[32], uint64_t counter, uint64_t stream, uint32_t out[16]) {
+    if (!key || !out) return fhe::fail("null pointer");
+    fhe::chacha20_block(fhe::seed_from_bytes(key), counter, stream, out);
+    return 0;
+}
+
+int fhe_client_key_create(const fhe_params_t* params, const uint8_t seed[32], fhe_client_key** out) {
     if (!out) return fhe::fail("null pointer: out");
     *out = nullptr;
     if (!params) return fhe::fail("null pointer: params");
+    if (!seed) return fhe::fail("null pointer: seed");
     try {
-        *out = new fhe_client_key{new fhe::ClientKey(*params, seed)};
+        *out = new fhe_client_key{new fhe::ClientKey(*params, fhe::seed_from_bytes(seed))};
     } catch (const std::exception& e) {
         return fhe::fail(e.what());
     }

@@ -56,26 +56,62 @@ FHE_HD double round_half_away(double x) {
     return t;
 }
 
-// xoshiro256** seeded through splitmix64, one independent stream per (seed, stream id)
+// 256-bit seed = ChaCha20 key.  Everything random on the client side and in server-key generation --
+// secret keys, masks, noise -- is ChaCha20 keystream under this key, one independent stream per
+// (purpose, row) through the 64-bit nonce.  Keystream is public-safe: the masks published in every
+// ciphertext and key row are outputs of a PRF and reveal neither the seed nor any other part of any
+// stream (the noise, the secret keys).  Stands in for the reference's AES-128-CTR generator with forked
+// byte ranges (concrete-csprng/src/generators, core_crypto/commons/generators/encryption.rs); the seed
+// comes from the OS (fhe_random_seed) unless a test fixes it.
+struct Seed256 {
+    uint32_t w[8];
+};
+
+FHE_HD Seed256 seed_from_bytes(const uint8_t b[32]) {     // little-endian words, as RFC 8439 loads a key
+    Seed256 s;
+    for (int i = 0; i < 8; i++)
+        s.w[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
+    return s;
+}
+
+// The ChaCha20 block function (D. J. Bernstein, 20 rounds; RFC 8439 section 2.3 with the original 64-bit
+// counter / 64-bit nonce split of words 12..15).
+FHE_HD void chacha20_block(const Seed256& key, uint64_t counter, uint64_t stream, uint32_t out[16]) {
+    uint32_t x[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
+                      key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7],
+                      (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+    uint32_t in[16];
+    for (int i = 0; i < 16; i++) in[i] = x[i];
+#define FHE_ROTL32(v, n) (((v) << (n)) | ((v) >> (32 - (n))))
+#define FHE_QR(a, b, c, d)                                  \
+    x[a] += x[b]; x[d] ^= x[a]; x[d] = FHE_ROTL32(x[d], 16); \
+    x[c] += x[d]; x[b] ^= x[c]; x[b] = FHE_ROTL32(x[b], 12); \
+    x[a] += x[b]; x[d] ^= x[a]; x[d] = FHE_ROTL32(x[d], 8);  \
+    x[c] += x[d]; x[b] ^= x[c]; x[b] = FHE_ROTL32(x[b], 7);
+    for (int r = 0; r < 10; r++) {
+        FHE_QR(0, 4, 8, 12) FHE_QR(1, 5, 9, 13) FHE_QR(2, 6, 10, 14) FHE_QR(3, 7, 11, 15)
+        FHE_QR(0, 5, 10, 15) FHE_QR(1, 6, 11, 12) FHE_QR(2, 7, 8, 13) FHE_QR(3, 4, 9, 14)
+    }
+#undef FHE_QR
+#undef FHE_ROTL32
+    for (int i = 0; i < 16; i++) out[i] = x[i] + in[i];
+}
+
+// Sequential reader of one stream: 64-bit words, little endian, 8 per block.
 struct Rng {
-    uint64_t s[4];
-    FHE_HD static uint64_t splitmix(uint64_t& x) {
-        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        return z ^ (z >> 31);
-    }
-    FHE_HD Rng(uint64_t seed, uint64_t stream) {
-        uint64_t x = seed ^ (stream * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull);
-        for (int i = 0; i < 4; i++) s[i] = splitmix(x);
-    }
-    FHE_HD static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    Seed256 key;
+    uint64_t stream, counter;
+    uint32_t buf[16];
+    int pos;
+    FHE_HD Rng(const Seed256& seed, uint64_t stream_id) : key(seed), stream(stream_id), counter(0), pos(16) {}
     FHE_HD uint64_t next() {
-        const uint64_t result = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
-        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
-        s[2] ^= t;
-        s[3] = rotl(s[3], 45);
-        return result;
+        if (pos >= 16) {
+            chacha20_block(key, counter++, stream, buf);
+            pos = 0;
+        }
+        const uint64_t v = (uint64_t)buf[pos] | ((uint64_t)buf[pos + 1] << 32);
+        pos += 2;
+        return v;
     }
 };
 

@@ -69,7 +69,7 @@ struct Engine {
     int use();
     int set_variant(int logR);
     int load_keys(const uint64_t* bsk_std, const uint64_t* ksk);
-    int generate_keys(const uint64_t* glwe_sk, const uint64_t* small_sk, uint64_t seed,
+    int generate_keys(const uint64_t* glwe_sk, const uint64_t* small_sk, const uint8_t seed[32],
                       uint64_t* bsk_std_out, uint64_t* ksk_out);
     int install_keys(uint64_t* d_ksk_std, uint64_t* d_bsk_std);
     uint64_t fill_accumulator(const uint64_t* table, std::vector<uint64_t>& acc) const { return fhe::fill_accumulator(p, table, acc); }

@@ -262,7 +262,7 @@ int Engine::load_keys(const uint64_t* bsk_std, const uint64_t* ksk) {
 
 // Server-key generation on the device (keygen_kernels.hip.h); replaces ServerKey::new
 // (shortint/engine/server_side.rs:54-160) for callers that hold the secret keys next to the GPU.
-int Engine::generate_keys(const uint64_t* glwe_sk, const uint64_t* small_sk, uint64_t seed,
+int Engine::generate_keys(const uint64_t* glwe_sk, const uint64_t* small_sk, const uint8_t seed[32],
                           uint64_t* bsk_std_out, uint64_t* ksk_out) {
     if (use()) return 1;
     const size_t in_dim = (size_t)p.k * p.N;
@@ -290,7 +290,7 @@ int Engine::generate_keys(const uint64_t* glwe_sk, const uint64_t* small_sk, uin
     if (e == hipSuccess) e = hipMemcpyAsync(d_gsk, glwe_sk, in_dim * 8, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_ssk, small_sk, (size_t)p.n * 8, hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) { cleanup(); return fail(std::string("generate_keys: ") + hipGetErrorString(e)); }
-    KeygenArgs a{d_gsk, d_ssk, d_bits, d_ksk_std, d_bsk_std, seed, p.n, p.k, p.N,
+    KeygenArgs a{d_gsk, d_ssk, d_bits, d_ksk_std, d_bsk_std, seed_from_bytes(seed), p.n, p.k, p.N,
                  p.pbs_base_log, p.pbs_level, p.ks_base_log, p.ks_level, p.lwe_std, p.glwe_std};
     hipLaunchKernelGGL(ksk_gen_kernel, dim3((unsigned)((in_dim + 63) / 64)), dim3(64), 0, stream, a);
     hipLaunchKernelGGL(bsk_gen_kernel, dim3(ng), dim3(256), 0, stream, a);

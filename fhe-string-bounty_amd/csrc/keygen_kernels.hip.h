@@ -6,7 +6,7 @@
 //                     glwe_encryption.rs:17-60)
 // Both write the reference's standard-domain layouts straight into HBM; the engine then runs its
 // usual conversions (ksk_pack_kernel / bsk_convert_kernel) without the keys ever visiting the host.
-// Randomness and noise are det_math.h's (one xoshiro256** stream per key row, polar Gaussian with a
+// Randomness and noise are det_math.h's (one ChaCha20 stream per key row, polar Gaussian with a
 // libm-free logarithm), drawn in the same order as client.cpp and oracle/tfhe_oracle.c, so the
 // generated keys are bit-identical to the CPU ones for the same (secret keys, seed) -- the parity
 // test compares them word for word.
@@ -26,7 +26,7 @@ struct KeygenArgs {
                                 // products of the group's key bits, engine.h multi_bit_key_bit)
     uint64_t* ksk;              // [k*N][ks_level][n+1]
     uint64_t* bsk;              // [n][pbs_level][k+1][k+1][N]
-    uint64_t seed;
+    Seed256 seed;               // ChaCha20 key (det_math.h)
     uint32_t n, k, N;
     uint32_t pbs_base_log, pbs_level, ks_base_log, ks_level;
     double lwe_std, glwe_std;

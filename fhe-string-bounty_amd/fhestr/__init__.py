@@ -112,6 +112,7 @@ EXPORTS = [
     "fhe_lwe_lincomb_batch", "fhe_last_kernel_ms", "fhe_kernel_times",
     "fhe_params_ksk_len", "fhe_params_bsk_len", "fhe_client_key_create", "fhe_client_key_destroy",
     "fhe_client_encrypt", "fhe_client_decrypt", "fhe_client_gen_server_keys", "fhe_client_secret_keys",
+    "fhe_random_seed", "fhe_chacha20_block",
     "fhe_plan_create", "fhe_plan_destroy", "fhe_plan_input", "fhe_plan_lut", "fhe_plan_lin", "fhe_plan_pbs",
     "fhe_plan_output", "fhe_plan_finalize", "fhe_plan_info", "fhe_plan_level_info", "fhe_plan_export_level",
     "fhe_plan_run", "fhe_plan_run_level_rank_dev", "fhe_plan_gather_outputs_dev", "fhe_str_plan_create",
@@ -162,7 +163,9 @@ def lib() -> C.CDLL:
     sig("fhe_engine_destroy", vp)
     sig("fhe_engine_params", vp, PP)
     sig("fhe_engine_load_keys", vp, vp, vp)
-    sig("fhe_engine_generate_keys", vp, vp, vp, C.c_uint64, vp, vp)
+    sig("fhe_engine_generate_keys", vp, vp, vp, vp, vp, vp)
+    sig("fhe_random_seed", vp)
+    sig("fhe_chacha20_block", vp, C.c_uint64, C.c_uint64, vp)
     sig("fhe_engine_synchronize", vp)
     sig("fhe_engine_set_variant", vp, i32)
     sig("fhe_lut_generate", vp, vp, C.POINTER(u32), C.POINTER(C.c_uint64))
@@ -177,7 +180,7 @@ def lib() -> C.CDLL:
     sig("fhe_lwe_lincomb_batch", vp, vp, u32, vp, vp, vp, vp, vp, u32)
     sig("fhe_last_kernel_ms", vp, C.POINTER(C.c_float))
     sig("fhe_kernel_times", vp, C.POINTER(C.c_double), C.POINTER(u32), i32)
-    sig("fhe_client_key_create", PP, C.c_uint64, C.POINTER(vp))
+    sig("fhe_client_key_create", PP, vp, C.POINTER(vp))
     sig("fhe_client_key_destroy", vp)
     sig("fhe_client_encrypt", vp, vp, u32, vp)
     sig("fhe_client_decrypt", vp, vp, u32, vp)
@@ -233,6 +236,30 @@ def lib() -> C.CDLL:
         getattr(L, name).argtypes = [PP]
     _lib = L
     return L
+
+
+def seed_bytes(seed) -> bytes:
+    """256-bit seed (ChaCha20 key) as 32 bytes.  Tests pass small integers (little endian, zero extended);
+    production code passes random_seed()."""
+    if isinstance(seed, (bytes, bytearray)):
+        if len(seed) != 32:
+            raise FheError("a seed is 32 bytes")
+        return bytes(seed)
+    return int(seed).to_bytes(32, "little")
+
+
+def random_seed() -> bytes:
+    """32 bytes from the OS CSPRNG (fhe_random_seed)."""
+    buf = (C.c_uint8 * 32)()
+    _check(lib().fhe_random_seed(buf))
+    return bytes(buf)
+
+
+def chacha20_block(key: bytes, counter: int, stream: int) -> np.ndarray:
+    out = np.zeros(16, dtype=np.uint32)
+    kb = (C.c_uint8 * 32)(*seed_bytes(key))
+    _check(lib().fhe_chacha20_block(kb, C.c_uint64(counter), C.c_uint64(stream), _ptr(out)))
+    return out
 
 
 def noise_model(params: "Params") -> dict:
@@ -317,7 +344,8 @@ class Engine:
             raise FheError("secret key size mismatch")
         bsk = np.zeros(p.bsk_len, dtype=np.uint64) if export else None
         ksk = np.zeros(p.ksk_len, dtype=np.uint64) if export else None
-        _check(lib().fhe_engine_generate_keys(self._h, _ptr(glwe_sk), _ptr(small_sk), C.c_uint64(seed),
+        sb = (C.c_uint8 * 32)(*seed_bytes(seed))
+        _check(lib().fhe_engine_generate_keys(self._h, _ptr(glwe_sk), _ptr(small_sk), sb,
                                               _ptr(bsk) if export else None, _ptr(ksk) if export else None))
         return (bsk, ksk) if export else None
 
@@ -432,10 +460,12 @@ class Engine:
 class ClientKey:
     """Client side (CPU): mirrors shortint::ClientKey (tfhe/src/shortint/client_key/mod.rs)."""
 
-    def __init__(self, params: Params, seed: int):
+    def __init__(self, params: Params, seed):
+        """seed: 32 bytes (random_seed()) or, for reproducible tests, an int."""
         self.params = params
         self._h = C.c_void_p()
-        _check(lib().fhe_client_key_create(C.byref(params.c()), seed, C.byref(self._h)))
+        sb = (C.c_uint8 * 32)(*seed_bytes(seed))
+        _check(lib().fhe_client_key_create(C.byref(params.c()), sb, C.byref(self._h)))
 
     def close(self):
         if self._h:

@@ -69,7 +69,7 @@ int fhe_engine_load_keys(fhe_engine *eng, const uint64_t *bsk_std, const uint64_
  * the keys are bit-identical.  bsk_std_out / ksk_out (either may be NULL) receive the standard-domain
  * keys (fhe_params_{bsk,ksk}_len words). */
 int fhe_engine_generate_keys(fhe_engine *eng, const uint64_t *glwe_sk, const uint64_t *small_sk,
-                             uint64_t seed, uint64_t *bsk_std_out, uint64_t *ksk_out);
+                             const uint8_t seed[32], uint64_t *bsk_std_out, uint64_t *ksk_out);
 /* The engine's HIP stream (hipStream_t) so callers can order their own work against it. */
 void *fhe_engine_stream(fhe_engine *eng);
 /* Launch on a caller-owned hipStream_t instead (NULL = HIP's default stream), e.g. the framework
@@ -267,11 +267,19 @@ int fhe_str_to_lower(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_
 /* ---- client side (CPU): keys, encryption, decryption ---------------------------------------- */
 /* ClientKey::new / encrypt / decrypt_message_and_carry / ServerKey::new of the reference
  * (shortint/engine/client_side.rs:13-128, shortint/client_key/mod.rs:281-337,
- * shortint/engine/server_side.rs:54-160).  Deterministic from `seed`. */
+ * shortint/engine/server_side.rs:54-160).
+ * Randomness: all of it -- secret keys, masks, noise -- is ChaCha20 keystream under the 256-bit `seed`
+ * (one stream per purpose and key row; stands in for the reference's AES-128-CTR concrete-csprng with
+ * forked generators).  Published masks are PRF output and reveal neither the seed nor the noise.  Take
+ * the seed from fhe_random_seed (the OS CSPRNG) in production; a fixed seed reproduces every key and
+ * ciphertext bit for bit and is for tests only.  The seed is as secret as the secret keys. */
 typedef struct fhe_client_key fhe_client_key;
+int fhe_random_seed(uint8_t seed[32]);
+/* the block function itself (known-answer tests): out = ChaCha20(key; words 12,13 = counter, 14,15 = stream) */
+int fhe_chacha20_block(const uint8_t key[32], uint64_t counter, uint64_t stream, uint32_t out[16]);
 size_t fhe_params_ksk_len(const fhe_params_t *p);
 size_t fhe_params_bsk_len(const fhe_params_t *p);
-int fhe_client_key_create(const fhe_params_t *params, uint64_t seed, fhe_client_key **out);
+int fhe_client_key_create(const fhe_params_t *params, const uint8_t seed[32], fhe_client_key **out);
 int fhe_client_key_destroy(fhe_client_key *ck);
 /* msgs[i] in [0, msg_mod*carry_mod); cts: count x (kN+1) u64 (big-key encryption, glwe noise). */
 int fhe_client_encrypt(fhe_client_key *ck, const uint64_t *msgs, uint32_t count, uint64_t *cts);

@@ -168,17 +168,18 @@ def lib() -> C.CDLL:
     sig("orc_ks_pbs_batch", None, P, _u64p, vp, vp, i32, _u64p, vp, _u64p, _u64p, sz, i32)
     sig("orc_fill_accumulator", u64, P, _u64p, _u64p)
     sig("orc_trivial_pbs_body", u64, P, u64, _u64p)
-    sig("orc_gen_binary_key", None, u64, u64, _u64p, sz)
+    sig("orc_gen_binary_key", None, C.c_char_p, u64, _u64p, sz)
     sig("orc_lwe_encrypt", None, _u64p, sz, u64, dbl, vp, _u64p)
     sig("orc_lwe_decrypt", u64, _u64p, sz, _u64p)
-    sig("orc_gen_ksk", None, P, _u64p, _u64p, u64, _u64p)
-    sig("orc_gen_bsk", None, P, _u64p, _u64p, u64, _u64p, i32)
+    sig("orc_gen_ksk", None, P, _u64p, _u64p, C.c_char_p, _u64p)
+    sig("orc_gen_bsk", None, P, _u64p, _u64p, C.c_char_p, _u64p, i32)
     sig("orc_encode", u64, P, u64)
     sig("orc_decode", u64, P, u64)
     sig("orc_multi_bit_key_bits", None, _u64p, u32, u32, _u64p)
     sig("orc_multi_bit_pbs_fft", None, P, u32, vp, _f64p, _u64p, _u64p, _u64p)
     sig("orc_multi_bit_pbs_exact", None, P, u32, _u64p, _u64p, _u64p, _u64p)
-    sig("orc_rng_init", None, vp, u64, u64)
+    sig("orc_rng_init", None, vp, C.c_char_p, u64)
+    sig("orc_chacha20_block", None, C.c_char_p, u64, u64, vp)
     sig("orc_rng_next", u64, vp)
     _lib = L
     return L
@@ -239,10 +240,26 @@ def f64_to_i64(x: float) -> int:
 
 
 # --------------------------------------------------------------------- client side (harness)
+def seed_bytes(seed) -> bytes:
+    """256-bit seed (ChaCha20 key): 32 bytes, or an int for tests (little endian, zero extended)."""
+    if isinstance(seed, (bytes, bytearray)):
+        assert len(seed) == 32
+        return bytes(seed)
+    return int(seed).to_bytes(32, "little")
+
+
+def chacha20_block(key: bytes, counter: int, stream: int) -> np.ndarray:
+    out = np.zeros(16, dtype=np.uint32)
+    lib().orc_chacha20_block(seed_bytes(key), counter, stream, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 class Rng:
-    def __init__(self, seed: int, stream: int = 0):
-        self.buf = (C.c_uint64 * 4)()
-        lib().orc_rng_init(C.addressof(self.buf), seed, stream)
+    """Sequential reader of one ChaCha20 stream of the harness generator (orc_rng)."""
+
+    def __init__(self, seed, stream: int = 0):
+        self.buf = (C.c_uint64 * 16)()          # >= sizeof(orc_rng) = 32 + 16 + 64 + 4 (+ padding)
+        lib().orc_rng_init(C.addressof(self.buf), seed_bytes(seed), stream)
 
     def next(self) -> int:
         return int(lib().orc_rng_next(C.addressof(self.buf)))
@@ -262,8 +279,8 @@ class ClientKey:
         self.seed = seed
         self.glwe_sk = np.zeros(params.k * params.N, dtype=np.uint64)
         self.small_sk = np.zeros(params.n, dtype=np.uint64)
-        lib().orc_gen_binary_key(seed, 1, self.glwe_sk, self.glwe_sk.size)
-        lib().orc_gen_binary_key(seed, 2, self.small_sk, self.small_sk.size)
+        lib().orc_gen_binary_key(seed_bytes(seed), 1, self.glwe_sk, self.glwe_sk.size)
+        lib().orc_gen_binary_key(seed_bytes(seed), 2, self.small_sk, self.small_sk.size)
         self.big_sk = self.glwe_sk  # client_side.rs:29
         self._rng = Rng(seed, 3)
 
@@ -306,9 +323,9 @@ class ServerKey:
         self.threads = threads or min(8, os.cpu_count() or 1)
         pc = p.c()
         self.ksk = np.zeros(p.big_dim * p.ks_level * p.small_size, dtype=np.uint64)
-        lib().orc_gen_ksk(C.byref(pc), ck.big_sk, ck.small_sk, ck.seed, self.ksk)
+        lib().orc_gen_ksk(C.byref(pc), ck.big_sk, ck.small_sk, seed_bytes(ck.seed), self.ksk)
         self.bsk = np.zeros(p.n * p.pbs_level * (p.k + 1) ** 2 * p.N, dtype=np.uint64)
-        lib().orc_gen_bsk(C.byref(pc), ck.small_sk, ck.glwe_sk, ck.seed, self.bsk, self.threads)
+        lib().orc_gen_bsk(C.byref(pc), ck.small_sk, ck.glwe_sk, seed_bytes(ck.seed), self.bsk, self.threads)
         self.fbsk = None
         if fourier:
             self.fbsk = np.zeros(self.bsk.size, dtype=np.float64)
@@ -384,11 +401,11 @@ class MultiBitServerKey:
         self.key_bits = np.zeros(self.n_ggsw, dtype=np.uint64)
         lib().orc_multi_bit_key_bits(ck.small_sk, p.n, grouping, self.key_bits)
         self.ksk = np.zeros(p.big_dim * p.ks_level * p.small_size, dtype=np.uint64)
-        lib().orc_gen_ksk(C.byref(p.c()), ck.big_sk, ck.small_sk, ck.seed, self.ksk)
+        lib().orc_gen_ksk(C.byref(p.c()), ck.big_sk, ck.small_sk, seed_bytes(ck.seed), self.ksk)
         # the multi-bit key is a list of n_ggsw constant GGSWs: the classic generator on that list
         self._pk = dataclasses.replace(p, n=self.n_ggsw)
         self.bsk = np.zeros(self.n_ggsw * p.pbs_level * (p.k + 1) ** 2 * p.N, dtype=np.uint64)
-        lib().orc_gen_bsk(C.byref(self._pk.c()), self.key_bits, ck.glwe_sk, ck.seed, self.bsk, self.threads)
+        lib().orc_gen_bsk(C.byref(self._pk.c()), self.key_bits, ck.glwe_sk, seed_bytes(ck.seed), self.bsk, self.threads)
         self.fbsk = np.zeros(self.bsk.size, dtype=np.float64)
         lib().orc_bsk_to_fourier(C.byref(self._pk.c()), self.bsk, self.fbsk)
         self._fft = lib().orc_fft_new(p.N)

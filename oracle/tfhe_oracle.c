@@ -715,32 +715,51 @@ uint64_t orc_trivial_pbs_body(const orc_params *p, uint64_t body_in, const uint6
 }
 
 /* ------------------------------------------------------------------------------------------
- * Harness.  The reference draws randomness from an AES-CTR CSPRNG (concrete-csprng, out of
- * scope: never used during evaluation); the harness uses xoshiro256** seeded by splitmix64 so
- * that fixtures are reproducible from a seed.
+ * Harness.  The reference draws randomness from an AES-128-CTR CSPRNG with forked generators
+ * (concrete-csprng, core_crypto/commons/generators; never used during evaluation).  The harness uses
+ * ChaCha20 keystream under a 256-bit seed, one stream per (purpose, key row) through the 64-bit
+ * nonce, so that fixtures are reproducible from a seed and the engine's client / device key
+ * generation (which uses the same construction) can be compared bit for bit.
  * ---------------------------------------------------------------------------------------- */
-static inline uint64_t splitmix64(uint64_t *x) {
-    uint64_t z = (*x += 0x9E3779B97F4A7C15ULL);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
+/* ChaCha20 block function: RFC 8439 section 2.3, with words 12,13 = 64-bit counter and words
+ * 14,15 = 64-bit stream id (the original counter / nonce split); pinned by the RFC's test vector in
+ * tests/test_oracle_kat.py */
+#define ORC_ROTL32(v, n) (((v) << (n)) | ((v) >> (32 - (n))))
+#define ORC_QR(a, b, c, d)                                   \
+    x[a] += x[b]; x[d] ^= x[a]; x[d] = ORC_ROTL32(x[d], 16); \
+    x[c] += x[d]; x[b] ^= x[c]; x[b] = ORC_ROTL32(x[b], 12); \
+    x[a] += x[b]; x[d] ^= x[a]; x[d] = ORC_ROTL32(x[d], 8);  \
+    x[c] += x[d]; x[b] ^= x[c]; x[b] = ORC_ROTL32(x[b], 7);
+void orc_chacha20_block(const uint8_t key[32], uint64_t counter, uint64_t stream, uint32_t out[16]) {
+    uint32_t x[16], in[16];
+    in[0] = 0x61707865u; in[1] = 0x3320646eu; in[2] = 0x79622d32u; in[3] = 0x6b206574u;
+    for (int i = 0; i < 8; i++)
+        in[4 + i] = (uint32_t)key[4 * i] | ((uint32_t)key[4 * i + 1] << 8) | ((uint32_t)key[4 * i + 2] << 16) |
+                    ((uint32_t)key[4 * i + 3] << 24);
+    in[12] = (uint32_t)counter; in[13] = (uint32_t)(counter >> 32);
+    in[14] = (uint32_t)stream;  in[15] = (uint32_t)(stream >> 32);
+    memcpy(x, in, sizeof x);
+    for (int r = 0; r < 10; r++) {
+        ORC_QR(0, 4, 8, 12) ORC_QR(1, 5, 9, 13) ORC_QR(2, 6, 10, 14) ORC_QR(3, 7, 11, 15)
+        ORC_QR(0, 5, 10, 15) ORC_QR(1, 6, 11, 12) ORC_QR(2, 7, 8, 13) ORC_QR(3, 4, 9, 14)
+    }
+    for (int i = 0; i < 16; i++) out[i] = x[i] + in[i];
 }
-static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
 
-void orc_rng_init(orc_rng *r, uint64_t seed, uint64_t stream) {
-    uint64_t x = seed ^ (stream * 0xD1342543DE82EF95ULL + 0x2545F4914F6CDD1DULL);
-    for (int i = 0; i < 4; i++) r->s[i] = splitmix64(&x);
+void orc_rng_init(orc_rng *r, const uint8_t seed[32], uint64_t stream) {
+    memcpy(r->key, seed, 32);
+    r->stream = stream;
+    r->counter = 0;
+    r->pos = 16;
 }
-uint64_t orc_rng_next(orc_rng *r) {
-    uint64_t *s = r->s;
-    uint64_t result = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
-    s[2] ^= s[0];
-    s[3] ^= s[1];
-    s[1] ^= s[2];
-    s[0] ^= s[3];
-    s[2] ^= t;
-    s[3] = rotl(s[3], 45);
-    return result;
+uint64_t orc_rng_next(orc_rng *r) {   /* 64-bit words, little endian, 8 per block */
+    if (r->pos >= 16) {
+        orc_chacha20_block(r->key, r->counter++, r->stream, r->buf);
+        r->pos = 0;
+    }
+    uint64_t v = (uint64_t)r->buf[r->pos] | ((uint64_t)r->buf[r->pos + 1] << 32);
+    r->pos += 2;
+    return v;
 }
 
 /* Natural logarithm of a normal, positive double from IEEE +,-,*,/ only (no libm): the noise sampler
@@ -797,7 +816,7 @@ static uint64_t gaussian_torus(orc_rng *r, double std) { /* gaussian.rs:85-97: f
 }
 
 /* shortint/engine/client_side.rs:13-27: uniform binary secret keys */
-void orc_gen_binary_key(uint64_t seed, uint64_t stream, uint64_t *key, size_t len) {
+void orc_gen_binary_key(const uint8_t seed[32], uint64_t stream, uint64_t *key, size_t len) {
     orc_rng r;
     orc_rng_init(&r, seed, stream);
     for (size_t i = 0; i < len; i += 64) {
@@ -844,7 +863,7 @@ void orc_glwe_encrypt_assign(const orc_params *p, const uint64_t *sk, uint64_t *
 /* core_crypto/algorithms/lwe_keyswitch_key_generation.rs:65-130: for each input key bit, an LWE
  * list under the small key encrypting bit << (64 - b*level), level = l..1 (highest first). */
 void orc_gen_ksk(const orc_params *p, const uint64_t *big_sk, const uint64_t *small_sk,
-                 uint64_t seed, uint64_t *ksk) {
+                 const uint8_t seed[32], uint64_t *ksk) {
     const size_t in_dim = (size_t)p->k * p->N, osz = (size_t)p->n + 1;
     for (size_t i = 0; i < in_dim; i++) {
         orc_rng r;
@@ -861,7 +880,7 @@ void orc_gen_ksk(const orc_params *p, const uint64_t *big_sk, const uint64_t *sm
 typedef struct {
     const orc_params *p;
     const uint64_t *small_sk, *glwe_sk;
-    uint64_t seed;
+    const uint8_t *seed;
     uint64_t *bsk;
     size_t lo, hi;
 } bsk_job;
@@ -897,7 +916,7 @@ static void *bsk_worker(void *arg) {
 }
 
 void orc_gen_bsk(const orc_params *p, const uint64_t *small_sk, const uint64_t *glwe_sk,
-                 uint64_t seed, uint64_t *bsk, int threads) {
+                 const uint8_t seed[32], uint64_t *bsk, int threads) {
     if (threads < 1) threads = 1;
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
     bsk_job *jobs = (bsk_job *)malloc(sizeof(bsk_job) * threads);

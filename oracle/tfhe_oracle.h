@@ -112,23 +112,27 @@ uint64_t orc_fill_accumulator(const orc_params *p, const uint64_t *table, uint64
 uint64_t orc_trivial_pbs_body(const orc_params *p, uint64_t body, const uint64_t *lut);
 
 /* ---- harness: deterministic PRNG, keys, encryption, decryption ---- */
-typedef struct {
-    uint64_t s[4];
+typedef struct {   /* sequential reader of one ChaCha20 stream (key = 256-bit seed, nonce = stream id) */
+    uint8_t key[32];
+    uint64_t stream, counter;
+    uint32_t buf[16];
+    int pos;
 } orc_rng;
-void orc_rng_init(orc_rng *r, uint64_t seed, uint64_t stream);
+void orc_chacha20_block(const uint8_t key[32], uint64_t counter, uint64_t stream, uint32_t out[16]);
+void orc_rng_init(orc_rng *r, const uint8_t seed[32], uint64_t stream);
 uint64_t orc_rng_next(orc_rng *r);
 void orc_rng_gaussian_pair(orc_rng *r, double std, double *a, double *b);
 
-void orc_gen_binary_key(uint64_t seed, uint64_t stream, uint64_t *key, size_t len);
+void orc_gen_binary_key(const uint8_t seed[32], uint64_t stream, uint64_t *key, size_t len);
 void orc_lwe_encrypt(const uint64_t *sk, size_t dim, uint64_t plaintext, double std, orc_rng *r,
                      uint64_t *ct);
 uint64_t orc_lwe_decrypt(const uint64_t *sk, size_t dim, const uint64_t *ct);
 void orc_glwe_encrypt_assign(const orc_params *p, const uint64_t *glwe_sk, uint64_t *glwe,
                              double std, orc_rng *r);
 void orc_gen_ksk(const orc_params *p, const uint64_t *big_sk, const uint64_t *small_sk,
-                 uint64_t seed, uint64_t *ksk);
+                 const uint8_t seed[32], uint64_t *ksk);
 void orc_gen_bsk(const orc_params *p, const uint64_t *small_sk, const uint64_t *glwe_sk,
-                 uint64_t seed, uint64_t *bsk_std, int threads);
+                 const uint8_t seed[32], uint64_t *bsk_std, int threads);
 uint64_t orc_encode(const orc_params *p, uint64_t msg);
 uint64_t orc_decode(const orc_params *p, uint64_t plaintext); /* message AND carry */
 

@@ -41,7 +41,9 @@ typedef struct {
 
 static ctx_t setup(void) {
     ctx_t c;
-    CHECK(fhe_client_key_create(&P22, 0xC0FFEE, &c.ck));
+    /* a fixed 256-bit seed: tests only -- production callers take it from fhe_random_seed() */
+    static const uint8_t seed[32] = {0xEE, 0xFF, 0xC0};
+    CHECK(fhe_client_key_create(&P22, seed, &c.ck));
     uint64_t *bsk = malloc(fhe_params_bsk_len(&P22) * sizeof(uint64_t));
     uint64_t *ksk = malloc(fhe_params_ksk_len(&P22) * sizeof(uint64_t));
     EXPECT(bsk && ksk);

@@ -16,22 +16,21 @@ PARAM_SETS = [O.TOY_K1, O.TOY_K2, O.PARAM_MESSAGE_2_CARRY_2_KS_PBS]
 
 
 def _phase_tolerance(p):
-    """Bound on |phase_gpu - phase_oracle| (phase = b - <a, s>, the only quantity two f64
-    implementations can be compared on: one flipped decomposition digit re-randomises the mask
-    coefficients while moving the phase by noise only).
+    """Bound on |phase_gpu - phase_oracle| (phase = b - <a, s>, the only quantity two f64 implementations
+    can be compared on: one flipped decomposition digit re-randomises the mask coefficients while moving
+    the phase by noise only).
 
-    One f64 negacyclic product is allowed 2^(64 - (52 - digit_bits - log2 N)) per coefficient by the
-    reference (fft/tests.rs:166-173).  A PBS output coefficient sums n*(k+1)*level such products
-    (in quadrature) and the phase sums kN/2 key-selected coefficients (again in quadrature).
-    On top of that, a coefficient sitting on a rounding boundary of closest_representable
-    (decomposer.rs:98-118) may round the other way under a 2^-30 perturbation; each such flip
-    moves the phase by one decomposition granule 2^(64 - base_log*level) times a key coefficient --
-    bounded here by the full rounding-noise budget of the blind rotation."""
-    logN = p.N.bit_length() - 1
-    one = 2.0 ** (64 - (52 - p.pbs_base_log - logN))
-    fft = one * np.sqrt(p.n * p.pbs_level * (p.k + 1)) * np.sqrt(p.k * p.N / 2)
-    granule = 2.0 ** (64 - p.pbs_base_log * p.pbs_level)
-    return fft + granule * np.sqrt(p.n * (p.k * p.N / 2 + 1))
+    With a 2^23 base the f64 FFT's rounding (~2^40 per accumulator coefficient and CMUX step) is as large
+    as the decomposition granule (2^41), so after a few of the n steps the two accumulators round
+    differently and the two outputs are, in effect, two independent draws of the same PBS output noise:
+    their phase difference has variance 2 V_pbs.  V_pbs is the engine's noise model (csrc/noise_model.h:
+    GGSW noise + decomposition rounding + FFT rounding; its value is itself checked against the measured
+    PBS output noise in tests/test_gpu_noise.py).  8 standard deviations of that difference:
+    PARAM_MESSAGE_2_CARRY_2 -> 2^52.1 against 2^50.3 .. 2^51.0 measured over 48 samples, delta/2 = 2^58."""
+    import fhestr
+    from conftest import to_fhestr_params
+    v_pbs = fhestr.noise_model(to_fhestr_params(p))["v_pbs"]
+    return 8.0 * np.sqrt(2.0 * v_pbs) * 2.0**64
 
 
 def _phases(ks, cts):
@@ -116,15 +115,18 @@ def test_ks_pbs_decrypts_and_tracks_oracle(params):
     assert _phase_tolerance(params) < params.delta / 4
 
 
-@pytest.mark.parametrize("params", [O.TOY_K1, O.TOY_K2], ids=lambda p: p.name)
+@pytest.mark.parametrize("params", PARAM_SETS, ids=lambda p: p.name)
 def test_ks_pbs_tracks_exact_integer_oracle(params):
-    """Against the exact-integer external product (no FFT at all)."""
+    """Against the exact-integer external product (schoolbook negacyclic products mod 2^64, no FFT at all);
+    on the real parameter set too (8 ciphertexts: ~2 s of CPU each)."""
     ks = keyset(params)
     eng = gpu_engine(ks)
     M = params.msg_mod * params.carry_mod
     lut, _ = ks.sk.generate_lookup_table(lambda x: (M - 1 - x))
     lut_id = eng.upload_lut(lut)
-    cts = ks.ck.encrypt_many(range(M), O.Rng(77, 1))
+    msgs = list(range(M)) if params.N <= 256 else [0, 1, 5, 7, 8, 11, 14, 15]
+    M = len(msgs)
+    cts = ks.ck.encrypt_many(msgs, O.Rng(77, 1))
     got = eng.apply_lookup_table(cts, np.full(M, lut_id, dtype=np.uint32))
     want = ks.sk.apply_lookup_table_batch(cts, lut, exact=True)
     assert np.array_equal(ks.ck.decrypt_many(got), ks.ck.decrypt_many(want))

@@ -140,9 +140,37 @@ def test_keyswitch_doctest_message_survives():
     ck = O.ClientKey(p, 11)
     import ctypes as C
     ksk = np.zeros(p.big_dim * p.ks_level * p.small_size, dtype=np.uint64)
-    O.lib().orc_gen_ksk(C.byref(p.c()), ck.big_sk, ck.small_sk, 11, ksk)
+    O.lib().orc_gen_ksk(C.byref(p.c()), ck.big_sk, ck.small_sk, O.seed_bytes(11), ksk)
     ct = ck.encrypt_plaintext(3 << 60)
     out = np.zeros(p.small_size, dtype=np.uint64)
     O.lib().orc_keyswitch(C.byref(p.c()), ksk, ct, out)
     dec = ck.decrypt_small_plaintext(out)
     assert O.closest_representable(dec, 4, 1) >> 60 == 3
+
+
+def test_chacha20_block_rfc8439_vector():
+    """The harness / client generator's block function against RFC 8439 section 2.3.2 (key 00..1f, counter 1,
+    nonce 00:00:00:09:00:00:00:4a:00:00:00:00 = words 13, 14, 15), in the oracle and in libfhestr's twin."""
+    import fhestr
+    key = bytes(range(32))
+    counter, stream = 1 | (0x09000000 << 32), 0x4A000000
+    want = [0xe4e7f110, 0x15593bd1, 0x1fdd0f50, 0xc47120a3, 0xc7f4d1c7, 0x0368c033, 0x9aaa2204, 0x4e6cd4c3,
+            0x466482d2, 0x09aa9f07, 0x05d7c214, 0xa2028bd9, 0xd19c12b5, 0xb94e16de, 0xe883d0cb, 0x4e3c50a2]
+    assert O.chacha20_block(key, counter, stream).tolist() == want
+    assert fhestr.chacha20_block(key, counter, stream).tolist() == want
+
+
+def test_client_and_oracle_draw_the_same_stream():
+    """Same seed, same stream ids: the product's client keys equal the oracle's; different seeds differ; an
+    OS-entropy seed gives yet another key."""
+    import fhestr
+    from conftest import to_fhestr_params
+    p = O.TOY_K1
+    P = to_fhestr_params(p)
+    a = fhestr.ClientKey(P, 0x1234).secret_keys()
+    b = O.ClientKey(p, 0x1234)
+    assert np.array_equal(a[0], b.glwe_sk) and np.array_equal(a[1], b.small_sk)
+    assert not np.array_equal(fhestr.ClientKey(P, 0x1235).secret_keys()[0], a[0])
+    s1, s2 = fhestr.random_seed(), fhestr.random_seed()
+    assert len(s1) == 32 and s1 != s2
+    assert not np.array_equal(fhestr.ClientKey(P, s1).secret_keys()[0], fhestr.ClientKey(P, s2).secret_keys()[0])
