@@ -112,6 +112,8 @@ static const std::vector<BrVariant>& variants() {
         make_wide_variant<11, 2, 2, 1>(), make_wide_variant<11, 3, 2, 1>(),
         // PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS: multi-bit PBS, grouping factor 2
         make_multibit_variant<11, 2, 2, 2>(),
+        // PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS: grouping factor 3 (8 GGSWs per group)
+        make_multibit_variant<11, 2, 2, 3>(),
         // N=1024, k=2, l=1 family (PARAM_MESSAGE_2_CARRY_1_KS_PBS ...)
         make_variant<10, 3, 3, 1>(), make_variant<10, 2, 3, 1>(), make_wide_variant<10, 2, 3, 1>(),
         // PARAM_MESSAGE_1_CARRY_1_KS_PBS: N=512, k=3, l=1

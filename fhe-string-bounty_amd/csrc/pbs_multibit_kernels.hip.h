@@ -3,7 +3,8 @@
 // Replaces multi_bit_blind_rotate_assign / multi_bit_programmable_bootstrap_lwe_ciphertext
 //   tfhe/src/core_crypto/algorithms/lwe_multi_bit_programmable_bootstrapping.rs:18-83 (prepare_multi_bit_ggsw),
 //   :295-546 (blind rotation: one external product per group of G mask elements), :1035-1127 (PBS)
-// for the parameter shape of PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS (N = 2048, k = 1, one level).
+// for the parameter shape of PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_{2,3}_KS_PBS (N = 2048, k = 1, one
+// level; shortint/parameters/multi_bit.rs:115-135,173-190), grouping factors 2 and 3.
 //
 // The reference pipelines "build the group's GGSW" (CPU threads) against "external product"
 // (one thread).  Here one workgroup per LWE does both inside the step, thread-locally:
@@ -125,18 +126,23 @@ blind_rotate_multibit_kernel(BlindRotateArgs args) {
     for (uint32_t grp = 0; grp < groups; grp++) {
         // ---- request this group's 2^G GGSWs (column g, rows (g + r) % K1) now: they arrive from L2
         //      while the accumulator is decomposed and transformed ----
+        //      (grouping factor 2: all four at once; 3: two in flight, the next one requested while the
+        //      current one is folded in -- eight would need 256 VGPRs)
         const double2* gk = fbsk + (size_t)grp * (SEL + 1) * GGSW_ELEMS;
-        double2 gv[SEL + 1][K1][R];
-#pragma unroll
-        for (int s = 0; s <= SEL; s++) {
+        constexpr bool PREFETCH_ALL = (SEL + 1) * K1 * R * 4 <= 96;
+        constexpr int NBUF = PREFETCH_ALL ? SEL + 1 : 2;
+        double2 gv[NBUF][K1][R];
+        auto request = [&](int s) {
 #pragma unroll
             for (int r = 0; r < K1; r++) {
                 const int row = (g + r) % K1;
 #pragma unroll
                 for (int rho = 0; rho < R; rho++)
-                    gv[s][r][rho] = gk[(size_t)s * GGSW_ELEMS + ((size_t)row * K1 + g) * P + rho * T + tau];
+                    gv[s % NBUF][r][rho] = gk[(size_t)s * GGSW_ELEMS + ((size_t)row * K1 + g) * P + rho * T + tau];
             }
-        }
+        };
+#pragma unroll
+        for (int s = 0; s < NBUF; s++) request(s);
 
         // ---- external product acc <- GGSW (x) acc (ggsw.rs:477-598 on a zeroed destination) ----
         cplx x[K1][R];
@@ -164,6 +170,7 @@ blind_rotate_multibit_kernel(BlindRotateArgs args) {
             for (int rho = 0; rho < R; rho++) { comb[r][rho].re = gv[0][r][rho].x; comb[r][rho].im = gv[0][r][rho].y; }
 #pragma unroll
         for (int s = 1; s <= SEL; s++) {
+            if (!PREFETCH_ALL && s + 1 <= SEL) request(s + 1);      // into the buffer selector s-1 just left
             const uint32_t d = lds_deg[grp * SEL + (s - 1)];
             // monomial transform at slot rho: w^{d (1 - 4 f_tau)} * (-i)^{d rho}
             const uint32_t mi = (d * c_tau) & (2u * N - 1u);
@@ -180,7 +187,7 @@ blind_rotate_multibit_kernel(BlindRotateArgs args) {
             for (int rho = 0; rho < R; rho++) {
 #pragma unroll
                 for (int r = 0; r < K1; r++) {
-                    const double2 v = gv[s][r][rho];
+                    const double2 v = gv[s % NBUF][r][rho];
                     comb[r][rho].re = fma(v.x, mono.re, fma(-v.y, mono.im, comb[r][rho].re));
                     comb[r][rho].im = fma(v.x, mono.im, fma(v.y, mono.re, comb[r][rho].im));
                 }

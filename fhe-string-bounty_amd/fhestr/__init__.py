@@ -95,6 +95,10 @@ PARAM_MESSAGE_4_CARRY_4_KS_PBS = Params(996, 1, 32768, 15, 2, 3, 7, 16, 16,
 PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS = Params(818, 1, 2048, 22, 1, 5, 3, 4, 4,
                                                           0.000002226459789930014, 0.0000000000000003152931493498455,
                                                           "PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS", 2)
+# shortint/parameters/multi_bit.rs:173-190
+PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS = Params(888, 1, 2048, 21, 1, 7, 2, 4, 4,
+                                                          0.0000006125031601933181, 0.0000000000000003152931493498455,
+                                                          "PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS", 3)
 PARAM_MESSAGE_2_CARRY_1_KS_PBS = Params(742, 2, 1024, 23, 1, 4, 3, 4, 2,
                                         0.000007069849454709433, 0.00000000000000029403601535432533,
                                         "PARAM_MESSAGE_2_CARRY_1_KS_PBS")
@@ -113,6 +117,9 @@ EXPORTS = [
     "fhe_params_ksk_len", "fhe_params_bsk_len", "fhe_client_key_create", "fhe_client_key_destroy",
     "fhe_client_encrypt", "fhe_client_decrypt", "fhe_client_gen_server_keys", "fhe_client_secret_keys",
     "fhe_random_seed", "fhe_chacha20_block",
+    "fhe_wire_write_lwe_ciphertext", "fhe_wire_read_lwe_ciphertext", "fhe_wire_write_keyswitch_key",
+    "fhe_wire_read_keyswitch_key", "fhe_wire_write_bootstrap_key", "fhe_wire_read_bootstrap_key",
+    "fhe_wire_write_shortint_ciphertext", "fhe_wire_read_shortint_ciphertext",
     "fhe_plan_create", "fhe_plan_destroy", "fhe_plan_input", "fhe_plan_lut", "fhe_plan_lin", "fhe_plan_pbs",
     "fhe_plan_output", "fhe_plan_finalize", "fhe_plan_info", "fhe_plan_level_info", "fhe_plan_export_level",
     "fhe_plan_run", "fhe_plan_run_level_rank_dev", "fhe_plan_gather_outputs_dev", "fhe_str_plan_create",

@@ -1,0 +1,117 @@
+"""tfhe-rs 0.5 wire format (serde + bincode 1.x) through the C ABI's fhe_wire_* entry points: thin ctypes
+marshalling only (include/fhestr.h, csrc/wire_format.cpp)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import FheError, Params, _check, _ptr, _u64, lib
+
+
+class _Meta(C.Structure):
+    _fields_ = [("degree", C.c_uint64), ("noise_level", C.c_uint64), ("message_modulus", C.c_uint64),
+                ("carry_modulus", C.c_uint64), ("pbs_order", C.c_uint32)]
+
+
+@dataclass
+class ShortintMeta:
+    """shortint::Ciphertext's metadata fields (shortint/ciphertext/mod.rs:261-270)."""
+    degree: int
+    noise_level: int = 1            # NoiseLevel::NOMINAL
+    message_modulus: int = 4
+    carry_modulus: int = 4
+    pbs_order: int = 0              # PBSOrder::KeyswitchBootstrap
+
+
+def _sigs():
+    L = lib()
+    if getattr(L, "_wire_ready", False):
+        return L
+    vp, sz = C.c_void_p, C.c_size_t
+    PP = C.POINTER(type(Params(1, 1, 1, 1, 1, 1, 1, 1, 1, 0.0, 0.0).c()))
+    szp = C.POINTER(sz)
+    for name, args in (
+            ("fhe_wire_write_lwe_ciphertext", [vp, sz, vp, sz, szp]),
+            ("fhe_wire_read_lwe_ciphertext", [vp, sz, vp, sz, szp, szp]),
+            ("fhe_wire_write_keyswitch_key", [PP, vp, vp, sz, szp]),
+            ("fhe_wire_read_keyswitch_key", [PP, vp, sz, vp, szp]),
+            ("fhe_wire_write_bootstrap_key", [PP, vp, vp, sz, szp]),
+            ("fhe_wire_read_bootstrap_key", [PP, vp, sz, vp, szp]),
+            ("fhe_wire_write_shortint_ciphertext", [vp, sz, C.POINTER(_Meta), C.c_int, vp, sz, szp]),
+            ("fhe_wire_read_shortint_ciphertext", [vp, sz, C.c_int, C.c_uint64, vp, sz, szp, C.POINTER(_Meta), szp])):
+        fn = getattr(L, name)
+        fn.restype = C.c_int
+        fn.argtypes = args
+    L._wire_ready = True
+    return L
+
+
+def _write(call) -> bytes:
+    n = C.c_size_t()
+    _check(call(None, 0, C.byref(n)))
+    buf = (C.c_uint8 * n.value)()
+    _check(call(buf, n.value, C.byref(n)))
+    return bytes(buf)
+
+
+def _in(data: bytes):
+    return (C.c_uint8 * max(1, len(data))).from_buffer_copy(data or b"\0")
+
+
+def write_lwe_ciphertext(ct) -> bytes:
+    ct = _u64(ct)
+    return _write(lambda out, cap, n: _sigs().fhe_wire_write_lwe_ciphertext(_ptr(ct), ct.size, out, cap, n))
+
+
+def read_lwe_ciphertext(data: bytes, max_words: int = 1 << 20):
+    """-> (ciphertext words, bytes consumed)"""
+    ct = np.zeros(max_words, dtype=np.uint64)
+    size, used = C.c_size_t(), C.c_size_t()
+    _check(_sigs().fhe_wire_read_lwe_ciphertext(_in(data), len(data), _ptr(ct), ct.size, C.byref(size), C.byref(used)))
+    return ct[:size.value].copy(), used.value
+
+
+def write_keyswitch_key(params: Params, ksk) -> bytes:
+    ksk = _u64(ksk)
+    if ksk.size != params.ksk_len:
+        raise FheError("key size mismatch")
+    return _write(lambda out, cap, n: _sigs().fhe_wire_write_keyswitch_key(C.byref(params.c()), _ptr(ksk), out, cap, n))
+
+
+def read_keyswitch_key(params: Params, data: bytes) -> np.ndarray:
+    ksk = np.zeros(params.ksk_len, dtype=np.uint64)
+    used = C.c_size_t()
+    _check(_sigs().fhe_wire_read_keyswitch_key(C.byref(params.c()), _in(data), len(data), _ptr(ksk), C.byref(used)))
+    return ksk
+
+
+def write_bootstrap_key(params: Params, bsk) -> bytes:
+    bsk = _u64(bsk)
+    if bsk.size != params.bsk_len:
+        raise FheError("key size mismatch")
+    return _write(lambda out, cap, n: _sigs().fhe_wire_write_bootstrap_key(C.byref(params.c()), _ptr(bsk), out, cap, n))
+
+
+def read_bootstrap_key(params: Params, data: bytes) -> np.ndarray:
+    bsk = np.zeros(params.bsk_len, dtype=np.uint64)
+    used = C.c_size_t()
+    _check(_sigs().fhe_wire_read_bootstrap_key(C.byref(params.c()), _in(data), len(data), _ptr(bsk), C.byref(used)))
+    return bsk
+
+
+def write_shortint_ciphertext(ct, meta: ShortintMeta, safe: bool = False) -> bytes:
+    ct = _u64(ct)
+    m = _Meta(meta.degree, meta.noise_level, meta.message_modulus, meta.carry_modulus, meta.pbs_order)
+    return _write(lambda out, cap, n: _sigs().fhe_wire_write_shortint_ciphertext(_ptr(ct), ct.size, C.byref(m), int(safe),
+                                                                                 out, cap, n))
+
+
+def read_shortint_ciphertext(data: bytes, safe: bool = False, size_limit: int = 0, max_words: int = 1 << 20):
+    """-> (ciphertext words, ShortintMeta, bytes consumed)"""
+    ct = np.zeros(max_words, dtype=np.uint64)
+    size, used, m = C.c_size_t(), C.c_size_t(), _Meta()
+    _check(_sigs().fhe_wire_read_shortint_ciphertext(_in(data), len(data), int(safe), size_limit, _ptr(ct), ct.size,
+                                                     C.byref(size), C.byref(m), C.byref(used)))
+    return ct[:size.value].copy(), ShortintMeta(m.degree, m.noise_level, m.message_modulus, m.carry_modulus, m.pbs_order), used.value

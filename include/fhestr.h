@@ -290,6 +290,36 @@ int fhe_client_gen_server_keys(fhe_client_key *ck, uint64_t *bsk_std, uint64_t *
 /* Copy out the secret keys (either pointer may be NULL): glwe_sk k*N u64, small_sk n u64. */
 int fhe_client_secret_keys(fhe_client_key *ck, uint64_t *glwe_sk, uint64_t *small_sk);
 
+/* ---- tfhe-rs wire format (serde + bincode 1.x, fixed-width little endian) ---------------------- */
+/* Byte forms of core_crypto's LweCiphertext<Vec<u64>>, LweKeyswitchKey<Vec<u64>>, standard-domain
+ * LweBootstrapKey<Vec<u64>> and shortint::Ciphertext as tfhe-rs 0.5 writes them with bincode::serialize /
+ * safe_serialize (entities/lwe_ciphertext.rs:500-507, lwe_keyswitch_key.rs:76-86,
+ * lwe_bootstrap_key.rs:98-106 + ggsw_ciphertext_list.rs:9-20, commons/ciphertext_modulus.rs:41-64,
+ * shortint/ciphertext/mod.rs:261-270, safe_deserialization.rs:16-99).  Native modulus 2^64 only.
+ * Writers: `out` may be NULL to query the size; *written receives the byte count either way.
+ * Readers validate every dimension against the parameter set (the reference's ParameterSetConformant)
+ * and never read past in_len.  The reference ships no serialized fixture: parity unpinned. */
+typedef struct fhe_shortint_meta {
+    uint64_t degree, noise_level, message_modulus, carry_modulus;
+    uint32_t pbs_order;   /* 0 = KeyswitchBootstrap, 1 = BootstrapKeyswitch (commons/parameters.rs:233-245) */
+} fhe_shortint_meta;
+int fhe_wire_write_lwe_ciphertext(const uint64_t *ct, size_t lwe_size, uint8_t *out, size_t out_cap, size_t *written);
+int fhe_wire_read_lwe_ciphertext(const uint8_t *in, size_t in_len, uint64_t *ct, size_t ct_cap, size_t *lwe_size,
+                                 size_t *consumed);
+int fhe_wire_write_keyswitch_key(const fhe_params_t *p, const uint64_t *ksk, uint8_t *out, size_t out_cap, size_t *written);
+int fhe_wire_read_keyswitch_key(const fhe_params_t *p, const uint8_t *in, size_t in_len, uint64_t *ksk, size_t *consumed);
+int fhe_wire_write_bootstrap_key(const fhe_params_t *p, const uint64_t *bsk_std, uint8_t *out, size_t out_cap,
+                                 size_t *written);
+int fhe_wire_read_bootstrap_key(const fhe_params_t *p, const uint8_t *in, size_t in_len, uint64_t *bsk_std,
+                                size_t *consumed);
+/* safe_framing != 0: the version / type-name header of safe_serialize; size_limit (0 = none) bounds the
+ * object's bytes like safe_deserialize's serialized_size_limit */
+int fhe_wire_write_shortint_ciphertext(const uint64_t *ct, size_t lwe_size, const fhe_shortint_meta *meta,
+                                       int safe_framing, uint8_t *out, size_t out_cap, size_t *written);
+int fhe_wire_read_shortint_ciphertext(const uint8_t *in, size_t in_len, int safe_framing, uint64_t size_limit,
+                                      uint64_t *ct, size_t ct_cap, size_t *lwe_size, fhe_shortint_meta *meta,
+                                      size_t *consumed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,7 +118,11 @@ TOY_SHAPES = [
 PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS = Params(818, 1, 2048, 22, 1, 5, 3, 4, 4,
                                                           0.000002226459789930014, 0.0000000000000003152931493498455,
                                                           "PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS")
+PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS = Params(888, 1, 2048, 21, 1, 7, 2, 4, 4,
+                                                          0.0000006125031601933181, 0.0000000000000003152931493498455,
+                                                          "PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS")
 TOY_MULTI_BIT_N2048 = Params(12, 1, 2048, 22, 1, 5, 3, 4, 4, 1e-13, 1e-17, "TOY_MULTI_BIT_N2048_G2")
+TOY_MULTI_BIT_N2048_G3 = Params(12, 1, 2048, 21, 1, 7, 2, 4, 4, 1e-13, 1e-17, "TOY_MULTI_BIT_N2048_G3")
 TOY_MULTI_BIT_N256 = Params(16, 1, 256, 10, 2, 4, 4, 4, 4, 1e-12, 1e-15, "TOY_MULTI_BIT_N256_G2")
 
 _u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")

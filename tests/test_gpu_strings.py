@@ -311,7 +311,7 @@ def test_general_replace_gpu(toy_k1, s, frm, to):
     es = _enc(toy_k1, s, 6)
     out_cap = max(len(want), 1)
     assert fhestr.blocks_to_string(P, _dec(toy_k1, ops.replace(es, frm, to, out_cap=out_cap))) == want
-    enc_out = ops.replace(es, _enc(toy_k1, frm, 3), _enc(toy_k1, to, 3), out_cap=10)
+    enc_out = ops.replace(es, _enc(toy_k1, frm, 3), _enc(toy_k1, to, 4), out_cap=10)
     assert fhestr.blocks_to_string(P, _dec(toy_k1, enc_out)) == want
 
 

@@ -14,20 +14,26 @@ from conftest import torus_distance
 
 G = 2
 TOY = O.TOY_MULTI_BIT_N2048
+TOY_G3 = O.TOY_MULTI_BIT_N2048_G3
 REAL = O.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS
+REAL_G3 = O.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS     # shortint/parameters/multi_bit.rs:173-190
 _KEYS = {}
+
+
+def _g(p):
+    return 3 if p.name.endswith("G3") or "GROUP_3" in p.name else 2
 
 
 def _fp(p):
     import fhestr
     return fhestr.Params(p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, p.ks_base_log, p.ks_level,
-                         p.msg_mod, p.carry_mod, p.lwe_std, p.glwe_std, p.name, G)
+                         p.msg_mod, p.carry_mod, p.lwe_std, p.glwe_std, p.name, _g(p))
 
 
 def _keys(p, seed=0x4D420001):
     if p.name not in _KEYS:
         ck = O.ClientKey(p, seed)
-        _KEYS[p.name] = (ck, O.MultiBitServerKey(ck, G))
+        _KEYS[p.name] = (ck, O.MultiBitServerKey(ck, _g(p)))
     return _KEYS[p.name]
 
 
@@ -40,7 +46,15 @@ def test_key_bits_follow_the_reference_selector_order():
     assert bits.reshape(4, 4).tolist() == [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]
 
 
-@pytest.mark.parametrize("p", [O.TOY_MULTI_BIT_N256, TOY], ids=lambda p: p.name)
+def test_key_bits_grouping_factor_3():
+    # selector bit g-1-b <-> key bit b of the group: GGSW `sel` encrypts prod_b (s_b if that bit is set else 1 - s_b)
+    sk = np.array([1, 0, 1], dtype=np.uint64)
+    bits = np.zeros(8, dtype=np.uint64)
+    O.lib().orc_multi_bit_key_bits(sk, 3, 3, bits)
+    assert bits.tolist() == [0, 0, 0, 0, 0, 1, 0, 0]          # only selector 0b101
+
+
+@pytest.mark.parametrize("p", [O.TOY_MULTI_BIT_N256, TOY, TOY_G3], ids=lambda p: p.name)
 def test_oracle_multi_bit_pbs_decrypts(p):
     ck, sk = _keys(p)
     M = p.msg_mod * p.carry_mod
@@ -58,15 +72,17 @@ def test_oracle_multi_bit_pbs_decrypts(p):
 
 def test_product_client_generates_the_oracle_multi_bit_keys():
     import fhestr
-    ck, sk = _keys(TOY)
-    pck = fhestr.ClientKey(_fp(TOY), ck.seed)
-    bsk, ksk = pck.gen_server_keys(2)
-    assert bsk.size == sk.bsk.size == TOY.n // G * 4 * 4 * TOY.N
-    assert np.array_equal(bsk, sk.bsk) and np.array_equal(ksk, sk.ksk)
+    for toy in (TOY, TOY_G3):
+        g = _g(toy)
+        ck, sk = _keys(toy)
+        pck = fhestr.ClientKey(_fp(toy), ck.seed)
+        bsk, ksk = pck.gen_server_keys(2)
+        assert bsk.size == sk.bsk.size == toy.n // g * (1 << g) * 4 * toy.N
+        assert np.array_equal(bsk, sk.bsk) and np.array_equal(ksk, sk.ksk)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("p", [TOY, REAL], ids=lambda p: p.name)
+@pytest.mark.parametrize("p", [TOY, REAL, TOY_G3, REAL_G3], ids=lambda p: p.name)
 def test_gpu_multi_bit_pbs_matches_oracle(p):
     import fhestr
     ck, sk = _keys(p)
@@ -98,7 +114,12 @@ def test_gpu_multi_bit_device_keygen_and_string_eq():
     """Device-side generation of the multi-bit key is bit-identical to the oracle's, and the string layer
     runs unchanged on top of a multi-bit engine."""
     import fhestr
-    p = TOY
+    for p in (TOY, TOY_G3):
+        _device_keygen_and_string_eq(p)
+
+
+def _device_keygen_and_string_eq(p):
+    import fhestr
     ck, sk = _keys(p)
     eng = fhestr.Engine(_fp(p), 0)
     try:
