@@ -188,6 +188,7 @@ int fhe_kernel_times(fhe_engine* eng, double total_ms[2], uint32_t* calls, int r
 namespace fhe {
 int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t b_cap,
                     const uint8_t* clear, uint32_t clear_len);
+int build_integer_op(Circuit& c, const std::string& op, uint32_t n_blocks, uint64_t scalar);
 }
 #include "noise_model.h"
 
@@ -332,6 +333,37 @@ static int str_plan(const fhe_params_t& params, fhe::Engine* eng, const char* op
     }
     *out = new fhe_plan{c, true};
     return 0;
+}
+
+static int int_plan(const fhe_params_t& params, fhe::Engine* eng, const char* op, uint32_t n_blocks, uint64_t scalar,
+                    uint32_t world, fhe_plan** out) {
+    fhe::Circuit* c = new fhe::Circuit(params, eng);
+    c->set_build_world(world);
+    if (fhe::build_integer_op(*c, op, n_blocks, scalar) || c->finalize(world)) {
+        delete c;
+        return 1;
+    }
+    *out = new fhe_plan{c, true};
+    return 0;
+}
+
+int fhe_int_plan_create(fhe_engine* eng, const char* op, uint32_t n_blocks, uint64_t scalar, uint32_t world, fhe_plan** out) {
+    API_BEGIN
+    CHECK_PTR(out);
+    *out = nullptr;
+    CHECK_PTR(eng); CHECK_PTR(op);
+    return int_plan(eng->impl->p, eng->impl, op, n_blocks, scalar, world, out);
+    API_END
+}
+
+int fhe_int_plan_create_offline(const fhe_params_t* params, const char* op, uint32_t n_blocks, uint64_t scalar,
+                                uint32_t world, fhe_plan** out) {
+    API_BEGIN
+    CHECK_PTR(out);
+    *out = nullptr;
+    CHECK_PTR(params); CHECK_PTR(op);
+    return int_plan(*params, nullptr, op, n_blocks, scalar, world, out);
+    API_END
 }
 
 int fhe_str_plan_create_offline(const fhe_params_t* params, const char* op, uint32_t a_cap, uint32_t b_cap,

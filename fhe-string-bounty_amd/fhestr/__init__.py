@@ -116,7 +116,7 @@ EXPORTS = [
     "fhe_lwe_lincomb_batch", "fhe_last_kernel_ms", "fhe_kernel_times",
     "fhe_params_ksk_len", "fhe_params_bsk_len", "fhe_client_key_create", "fhe_client_key_destroy",
     "fhe_client_encrypt", "fhe_client_decrypt", "fhe_client_gen_server_keys", "fhe_client_secret_keys",
-    "fhe_random_seed", "fhe_chacha20_block",
+    "fhe_random_seed", "fhe_chacha20_block", "fhe_int_plan_create", "fhe_int_plan_create_offline",
     "fhe_wire_write_lwe_ciphertext", "fhe_wire_read_lwe_ciphertext", "fhe_wire_write_keyswitch_key",
     "fhe_wire_read_keyswitch_key", "fhe_wire_write_bootstrap_key", "fhe_wire_read_bootstrap_key",
     "fhe_wire_write_shortint_ciphertext", "fhe_wire_read_shortint_ciphertext",
@@ -220,6 +220,8 @@ def lib() -> C.CDLL:
     sig("fhe_plan_set_owner_hint", vp, i32)
     sig("fhe_plan_gather_outputs_dev", vp, vp, vp)
     sig("fhe_str_plan_create", vp, C.c_char_p, u32, u32, vp, u32, u32, C.POINTER(vp))
+    sig("fhe_int_plan_create", vp, C.c_char_p, u32, C.c_uint64, u32, C.POINTER(vp))
+    sig("fhe_int_plan_create_offline", PP, C.c_char_p, u32, C.c_uint64, u32, C.POINTER(vp))
     sig("fhe_str_len", vp, vp, u32, vp)
     sig("fhe_str_is_empty", vp, vp, u32, vp)
     sig("fhe_str_strip_prefix_clear", vp, vp, u32, vp, u32, vp)
@@ -542,6 +544,18 @@ class Plan:
                                                      len(clear or b""), world, C.byref(h)))
         return cls(engine, h, params)
 
+    @classmethod
+    def integer_op(cls, engine: "Engine | None", op: str, n_blocks: int, scalar: int = 0, world: int = 1,
+                   params: Params | None = None) -> "Plan":
+        """Radix-integer operation on n_blocks blocks (include/fhestr.h, "radix-integer operations")."""
+        h = C.c_void_p()
+        if engine is not None:
+            _check(lib().fhe_int_plan_create(engine.handle, op.encode(), n_blocks, C.c_uint64(scalar), world, C.byref(h)))
+        else:
+            _check(lib().fhe_int_plan_create_offline(C.byref(params.c()), op.encode(), n_blocks, C.c_uint64(scalar),
+                                                     world, C.byref(h)))
+        return cls(engine, h, params)
+
     def export_luts(self) -> dict:
         """{plan-local LUT id: accumulator}."""
         n = C.c_uint32()
@@ -655,6 +669,17 @@ class Plan:
 
     def gather_outputs_dev(self, d_pool: int, d_out: int):
         _check(lib().fhe_plan_gather_outputs_dev(self._h, C.c_void_p(d_pool), C.c_void_p(d_out)))
+
+
+def int_to_blocks(params: Params, value: int, n_blocks: int) -> np.ndarray:
+    """Little-endian radix digits of an unsigned integer (integer/block_decomposition.rs:119-144)."""
+    bits = params.msg_mod.bit_length() - 1
+    return np.array([(value >> (bits * i)) & (params.msg_mod - 1) for i in range(n_blocks)], dtype=np.uint64)
+
+
+def blocks_to_int(params: Params, blocks) -> int:
+    bits = params.msg_mod.bit_length() - 1
+    return sum((int(b) % params.msg_mod) << (bits * i) for i, b in enumerate(np.asarray(blocks).reshape(-1)))
 
 
 def blocks_per_char(params: Params) -> int:

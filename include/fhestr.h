@@ -186,6 +186,22 @@ int fhe_plan_run(fhe_plan *plan, const uint64_t *inputs, uint64_t *outputs);
 int fhe_plan_run_level_rank_dev(fhe_plan *plan, uint64_t *d_pool, uint32_t level, uint32_t rank);
 int fhe_plan_gather_outputs_dev(fhe_plan *plan, const uint64_t *d_pool, uint64_t *d_out);
 
+/* ---- radix-integer operations (the reference's integer layer) -------------------------------- */
+/* An unsigned radix integer = n_blocks big-key LWE blocks, little endian, log2(msg_mod) bits each
+ * (integer/block_decomposition.rs:119-144).  A plan for one operation, run with fhe_plan_run (inputs in
+ * the order given) or sharded like any plan:
+ *   "add" "sub"                       a, b -> n_blocks blocks (wrapping): unchecked add + parallel one-carry
+ *                                     propagation + message_extract (radix_parallel/add.rs:487-624,724-772)
+ *   "scalar_add" "scalar_sub"         a, clear `scalar` (radix_parallel/scalar_add.rs:204-222)
+ *   "message_extract" "carry_extract" n_blocks blocks with full carries -> their messages / carries
+ *   "cmux"                            cond (0/1 block), t, f -> cond ? t : f (radix_parallel/cmux.rs:194-316)
+ *   "eq" "ne" "gt" "ge" "lt" "le"     a, b -> one 0/1 block (comparator.rs:193-280, scalar_comparison.rs:147-233)
+ *   "scalar_eq" ... "scalar_le"       a, clear `scalar` (at most 64 bits) */
+int fhe_int_plan_create(fhe_engine *eng, const char *op, uint32_t n_blocks, uint64_t scalar, uint32_t world,
+                        fhe_plan **out);
+int fhe_int_plan_create_offline(const fhe_params_t *params, const char *op, uint32_t n_blocks, uint64_t scalar,
+                                uint32_t world, fhe_plan **out);
+
 /* ---- FheString operations --------------------------------------------------------------------- */
 /* An encrypted string = `cap` characters, zero padded, each character 8/log2(msg_mod) big-key LWE
  * blocks, little endian (integer/block_decomposition.rs:119-144): cap * blocks * (kN+1) u64.

@@ -8,7 +8,8 @@ import fhestr
 rng = np.random.default_rng(0x5EED0003)
 hay = bytes(rng.integers(0x61, 0x7B, size=256, dtype=np.uint8))
 pat = hay[100:116]
-for P in (fhestr.PARAM_MESSAGE_2_CARRY_2_KS_PBS, fhestr.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS):
+for P in (fhestr.PARAM_MESSAGE_2_CARRY_2_KS_PBS, fhestr.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS,
+          fhestr.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS):
     ck = fhestr.ClientKey(P, 0x5EED0002)
     g, s = ck.secret_keys()
     eng = fhestr.Engine(P, 0)
