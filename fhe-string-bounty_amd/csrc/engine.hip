@@ -615,6 +615,12 @@ int Engine::kernel_times(double total_ms[2], uint32_t* calls, bool reset) {
     return 0;
 }
 
+#ifdef FHESTR_STAMPS
+extern "C" int fhe_debug_read_stamps(unsigned long long* out, size_t count) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), count * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
+
 int Engine::synchronize() {
     if (use()) return 1;
     HIP_TRY(hipStreamSynchronize(stream));

@@ -25,6 +25,28 @@
 
 namespace fhe {
 
+// Diagnostic build only (-DFHESTR_STAMPS, scripts/stamp_profile.py): s_memtime stamps around the
+// segments of one CMUX step of blind_rotate_kernel, summed per wave in scalar registers and stored once
+// after the loop into a buffer nothing else reads (cdna_hip_programming.md section 7, "In-kernel stamps").
+// The fences forbid overlaps the real kernel has: read the SHARES, never this build's run time.
+#ifdef FHESTR_STAMPS
+constexpr int STAMP_SEGS = 10;
+__device__ unsigned long long g_stamps[4096 * 8 * STAMP_SEGS];
+#define FHE_STAMP_DECL unsigned long long stamp_acc[STAMP_SEGS] = {}; unsigned long long stamp_prev = 0
+#define FHE_STAMP(idx)                                                                                   \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        unsigned long long _t;                                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                       \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if ((idx) >= 0) stamp_acc[(idx) < 0 ? 0 : (idx)] += _t - stamp_prev;                             \
+        stamp_prev = _t;                                                                                 \
+    } while (0)
+#else
+#define FHE_STAMP_DECL do {} while (0)
+#define FHE_STAMP(idx) do {} while (0)
+#endif
+
 struct BlindRotateArgs {
     const uint64_t* lwe_small;   // [B][n+1]
     const uint32_t* lut_idx;     // [B] or nullptr
@@ -75,10 +97,47 @@ __device__ __forceinline__ int32_t decomp_single_digit(uint64_t x, uint32_t b) {
     const uint32_t half = 1u << (b - 1);
     return (int32_t)(res - ((res + (half - 1u)) & (half << 1)));   // minus B iff res > B/2
 }
+// The same digit, biased: returns digit + (B/2 - 1) in [0, B) in two instructions.  With res = ((t+1)>>1) mod B
+// as above, digit + B/2 - 1 = (res + B/2 - 1) mod B (no wrap for res <= B/2, one wrap = the "minus B" for
+// res > B/2), and both the +1 of the rounding and the + B/2 - 1 are additions below the extracted field:
+// bits [32-b, 32) of hi + 2^(31-b) + (B/2 - 1) 2^(32-b) = hi + 2^31 - 2^(31-b)  (mod 2^32 = mod B up there).
+// The constant bias is taken out again for free: the caller converts the unsigned value to f64 and folds
+// -(B/2 - 1) (1 + i) * twist into the addend of the twist multiplication (digit_point).
+__device__ __forceinline__ uint32_t decomp_bias_constant(uint32_t b) {
+    uint32_t c = 0x80000000u - (1u << (31 - b));
+    asm volatile("" : "+s"(c));      // opaque: keeps hipcc from splitting the add into xor 2^31 + sub
+    return c;
+}
+__device__ __forceinline__ uint32_t decomp_single_biased(uint64_t x, uint32_t b, uint32_t bias_constant) {
+    const uint32_t hi = (uint32_t)(x >> 32);
+    return __builtin_amdgcn_ubfe(hi + bias_constant, 32u - b, b);
+}
+// (lo + i hi - c (1 + i)) * twist with the constant part kb = -c (1 + i) twist precomputed: 2 cvt + 4 fma
+__device__ __forceinline__ cplx digit_point(uint32_t lo_biased, uint32_t hi_biased, cplx tw, cplx kb) {
+    const double a = (double)lo_biased, b = (double)hi_biased;
+    cplx r;
+    r.re = fma(a, tw.re, fma(-b, tw.im, kb.re));
+    r.im = fma(a, tw.im, fma(b, tw.re, kb.im));
+    return r;
+}
 // fft_impl/common.rs:26-43 (offset 0, lut_count_log 0): result in [0, 2N]
 __device__ __forceinline__ uint32_t modulus_switch(uint64_t x, int logN) {
     uint64_t o = x >> (64 - logN - 2);
     return (uint32_t)((o + 1) >> 1);
+}
+
+// The Fourier key as a buffer resource (stride 0, raw): buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen
+// takes its row offset from a scalar register and bounds-checks against the key's size.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ auto key_resource(const double* fbsk, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(fbsk), 0, bytes < 0x7FFFFFF0u ? (int)bytes : 0x7FFFFFF0, 0x00020000);
+}
+template <class RSRC>
+__device__ __forceinline__ double2 key_load(RSRC rsrc, uint32_t voff, uint32_t soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
+    double2 d;
+    __builtin_memcpy(&d, &v, 16);
+    return d;
 }
 
 // LDS slot of coefficient j (< N) inside one polynomial's accumulator copy
@@ -95,33 +154,45 @@ template <class PL, int LOGN>
 struct Rotation {
     int32_t oddmask;
     uint32_t rem;        // generic plans
-    int32_t qb;          // swap plan: lane - rem/4 - borrow
-    uint32_t rbits;      // swap plan: ((w - rem) mod 4) << (LOGN - 2)
+    int32_t qb8;         // swap plan: 8 * (lane - rem/4 - borrow), plus 2^31 when the rotation count is odd
+    uint32_t rbits8;     // swap plan: byte offset of row ((w - rem) mod 4) of the transposed accumulator copy
     __device__ __forceinline__ Rotation(uint32_t d, int tau) {
         rem = d & ((1u << LOGN) - 1);
         oddmask = -(int32_t)((d >> LOGN) & 1);
         if constexpr (PL::SWAP) {
-            const int w = tau >> 6, lane = tau & 63;
+            const int w = __builtin_amdgcn_readfirstlane(tau >> 6), lane = tau & 63;   // wave index: scalar
             const int rr = (int)(rem & 3);
-            qb = lane - (int)(rem >> 2) - (w < rr ? 1 : 0);
-            rbits = (uint32_t)((w - rr) & 3) << (LOGN - 2);
+            // the sign of q = lane - rem/4 - borrow + const says "wrapped around"; adding 2^31 flips it when
+            // the whole polynomial is negated as well, so one arithmetic shift yields the negation mask
+            qb8 = (int32_t)((uint32_t)((lane - (int)(rem >> 2) - (w < rr ? 1 : 0)) << 3) + ((uint32_t)oddmask & 0x80000000u));
+            rbits8 = (uint32_t)((w - rr) & 3) << (LOGN - 2 + 3);
         } else {
-            qb = 0; rbits = 0;
+            qb8 = 0; rbits8 = 0;
         }
     }
     // slot of the source coefficient and its all-ones / all-zero negation mask
     __device__ __forceinline__ void source(int tau, int m, int h, uint32_t& slot, uint32_t& neg) const {
-        if constexpr (PL::SWAP) {
-            const int32_t q = qb + (PL::point(0, m) + h * PL::P) / 4;
-            neg = (uint32_t)((q >> 31) ^ oddmask);
-            slot = rbits | ((uint32_t)q & ((1u << (LOGN - 2)) - 1));
-        } else {
-            const uint32_t j = (uint32_t)PL::point(tau, m) + (uint32_t)h * PL::P;
-            neg = (uint32_t)(((int32_t)(j - rem) >> 31) ^ oddmask);   // j, rem < 2^31
-            slot = acc_slot_of<PL>((j - rem) & ((1u << LOGN) - 1));
-        }
+        static_assert(!PL::SWAP, "swap plan: use source_bytes");
+        const uint32_t j = (uint32_t)PL::point(tau, m) + (uint32_t)h * PL::P;
+        neg = (uint32_t)(((int32_t)(j - rem) >> 31) ^ oddmask);   // j, rem < 2^31
+        slot = acc_slot_of<PL>((j - rem) & ((1u << LOGN) - 1));
+    }
+    // swap plan: byte offset inside one polynomial's accumulator copy (to be OR-ed onto its 8N-aligned base:
+    // three instructions per coefficient -- add, and-or, arithmetic shift)
+    // `row_base` = the copy's base address | rbits8 (scalar, formed once per step by the caller)
+    __device__ __forceinline__ void source_bytes(int m, int h, uint32_t row_base, uint32_t& address, uint32_t& neg) const {
+        const int32_t q8 = qb8 + ((PL::point(0, m) + h * PL::P) / 4) * 8;
+        neg = (uint32_t)(q8 >> 31);
+        address = ((uint32_t)q8 & (((1u << (LOGN - 2)) - 1) << 3)) | row_base;       // v_and_or_b32
     }
 };
+
+// LDS access by byte address (32-bit, address space 3)
+typedef __attribute__((address_space(3))) const uint64_t lds_cu64_t;
+__device__ __forceinline__ uint32_t lds_address(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ uint64_t lds_load_u64(uint32_t byte_address) { return *(lds_cu64_t*)(uintptr_t)byte_address; }
 
 template <int LOGN, int LOGR, int K1, int L>
 struct BrCfg {
@@ -204,15 +275,24 @@ blind_rotate_kernel(BlindRotateArgs args) {
     double* lds_f = lds_x + (size_t)K1 * CFG::GROUP_SLOTS;                       // [K1][GROUP_SLOTS]
     uint32_t* lds_d = reinterpret_cast<uint32_t*>(lds_f + (size_t)K1 * CFG::GROUP_SLOTS);   // [n]
 
-    const int g = threadIdx.x / T, tau = threadIdx.x % T;
+    int g = threadIdx.x / T;
+    const int tau = threadIdx.x % T;
+    // a polynomial group is a whole number of wavefronts here: tell the compiler that g is wave-uniform,
+    // so the group-dependent address arithmetic (key rows, LDS planes) runs on the scalar unit
+    if constexpr (T % 64 == 0) g = __builtin_amdgcn_readfirstlane(g);
     const uint32_t sample = blockIdx.x;
     const uint32_t n = args.n;
     const uint64_t* lwe = args.lwe_small + (size_t)sample * (n + 1);
     const uint64_t* lut = args.luts + (size_t)(args.lut_idx ? args.lut_idx[sample] : 0) * K1 * N;
     uint64_t* my_acc = lds_acc + (size_t)g * N;
+    // byte address of this group's accumulator copy: 8N-aligned (the dynamic LDS segment starts at 0 and the
+    // copies come first), so the gather can OR its offsets onto it
+    const uint32_t my_acc_address = lds_address(my_acc);
+    if (PL::SWAP && (my_acc_address & (8u * N - 1u))) __builtin_trap();
     double* xre = lds_x + (size_t)g * CFG::GROUP_SLOTS;
     double* xim = xre + CFG::PLANE;
     const uint32_t bL = args.base_log * L;
+    const uint32_t dbias = decomp_bias_constant(bL <= 31 ? bL : 31);
 
     // modulus switch of the whole mask once (fft_impl/common.rs:26-43); a_i == 0 is skipped (:281)
     for (uint32_t i = threadIdx.x; i < n; i += CFG::THREADS) {
@@ -223,12 +303,15 @@ blind_rotate_kernel(BlindRotateArgs args) {
     // per-thread constants: inter-pass twiddles and twisties (1/P is folded into the Fourier key)
     FftConsts<PL> fc;
     fft_init_consts<PL>(fc, tau);
-    cplx twist[R];
+    cplx twist[R], twbias[R];        // twbias: -(B/2 - 1)(1 + i) * twist, the single-level digit's bias (decomp_single_biased)
 #pragma unroll
     for (int m = 0; m < R; m++) {
         double sn, cs;
         sincospi((double)PL::point(tau, m) / (double)N, &sn, &cs);
         twist[m].re = cs; twist[m].im = sn;
+        const double cb = -(double)((1u << (args.base_log * L - 1)) - 1u);
+        twbias[m].re = cb * (cs - sn);
+        twbias[m].im = cb * (cs + sn);
     }
 
     // acc <- LUT * X^{-ms(body)}   (bootstrap.rs:254-271, polynomial_algorithms.rs:331-353)
@@ -261,42 +344,65 @@ blind_rotate_kernel(BlindRotateArgs args) {
     constexpr size_t GGSW_ELEMS = (size_t)L * K1 * K1 * P;   // complex elements per GGSW
 
     uint32_t d_next = lds_d[0];
+    const uint32_t key_off = (uint32_t)tau * 16u;     // this thread's byte offset inside a Fourier polynomial row
+    const auto key_rsrc = key_resource(args.fbsk, (size_t)n * GGSW_ELEMS * 16);
+    FHE_STAMP_DECL;
+    FHE_STAMP(-1);
     for (uint32_t i = 0; i < n; i++) {
-        const uint32_t d = d_next;
+        // the modulus-switched mask element is the same for the whole workgroup: as a scalar, the rotation's
+        // uniform parts (quotient, remainder, sign) cost no vector instructions
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)d_next);
         d_next = lds_d[i + 1 < n ? i + 1 : i];                  // prefetch (LDS broadcast read)
         if (d == 0xFFFFFFFFu) continue;                          // block-uniform
         const Rotation<PL, LOGN> rot(d, tau);
 
         // Fourier GGSW rows of the last decomposition level handled first (ggsw.rs:524): issue the
-        // global loads now, they land while the forward FFT runs (L2 / Infinity-Cache resident key)
+        // loads now, they land while the forward FFT runs (L2 / Infinity-Cache resident key).  Buffer
+        // loads: the row's byte offset is a scalar (soffset), the thread's offset one constant VGPR -- no
+        // vector instruction is spent on addresses.
         const double2* bk0 = fbsk + (size_t)i * GGSW_ELEMS;
         double2 bpre[K1][R];
         {
-            const double2* bk = bk0 + (size_t)(L - 1) * K1 * K1 * P;
 #pragma unroll
             for (int r = 0; r < K1; r++) {
                 const int row = (g + r) % K1;       // r = 0 is this group's own row: branch-free below
 #pragma unroll
-                for (int rho = 0; rho < R; rho++) bpre[r][rho] = bk[((size_t)row * K1 + g) * P + rho * T + tau];
+                for (int rho = 0; rho < R; rho++) {
+                    const uint32_t soff = (uint32_t)((i * GGSW_ELEMS + (size_t)(L - 1) * K1 * K1 * P +
+                                                      ((size_t)row * K1 + g) * P + rho * T) * 16);
+                    bpre[r][rho] = key_load(key_rsrc, key_off, soff);
+                }
             }
         }
 
         // ct1 = acc * X^d - acc  (polynomial_algorithms.rs:463-489), then decomposition state
         uint32_t st_lo[R], st_hi[R];
+        uint32_t row_base = my_acc_address | rot.rbits8;         // scalar; opaque so that it stays ONE operand
+        if constexpr (PL::SWAP) asm volatile("" : "+s"(row_base));   // of the per-coefficient v_and_or_b32
 #pragma unroll
         for (int m = 0; m < R; m++) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                uint32_t slot, sm32;                             // (acc*X^d)[j] = +-acc[j - rem], select-free
-                rot.source(tau, m, h, slot, sm32);
+                uint32_t sm32;                                   // (acc*X^d)[j] = +-acc[j - rem], select-free
+                uint64_t gathered;
+                if constexpr (PL::SWAP) {
+                    uint32_t address;
+                    rot.source_bytes(m, h, row_base, address, sm32);
+                    gathered = lds_load_u64(address);
+                } else {
+                    uint32_t slot;
+                    rot.source(tau, m, h, slot, sm32);
+                    gathered = my_acc[slot];
+                }
                 const uint64_t sm = ((uint64_t)sm32 << 32) | sm32;
-                const uint64_t v = (my_acc[slot] ^ sm) - sm;
+                const uint64_t v = (gathered ^ sm) - sm;
                 const uint64_t own = h == 0 ? acc_lo[m] : acc_hi[m];
-                const uint32_t st = L == 1 ? (uint32_t)decomp_single_digit(v - own, bL) : decomp_init_state(v - own, bL);
+                const uint32_t st = L == 1 ? decomp_single_biased(v - own, bL, dbias) : decomp_init_state(v - own, bL);
                 if (h == 0) st_lo[m] = st; else st_hi[m] = st;
             }
         }
 
+        FHE_STAMP(0);    // key loads issued, rotation gather + decomposition (incl. the gather's LDS latency)
         cplx outf[R];
         if constexpr (PL::SWAP) {
             // Swap plan (single level): the forward transform's only workgroup barrier is also the
@@ -305,14 +411,21 @@ blind_rotate_kernel(BlindRotateArgs args) {
             static_assert(!PL::SWAP || L == 1, "swap plan: single decomposition level only");
             cplx x[K1][R];
 #pragma unroll
-            for (int m = 0; m < R; m++) {
-                cplx z;
-                z.re = (double)(int32_t)st_lo[m];
-                z.im = (double)(int32_t)st_hi[m];
-                x[0][m] = cmul(z, twist[m]);                     // fft/mod.rs:220-239
-            }
+            for (int m = 0; m < R; m++) x[0][m] = digit_point(st_lo[m], st_hi[m], twist[m], twbias[m]);   // fft/mod.rs:220-239
+#ifdef FHESTR_STAMPS
+            swap10_fwd_stage1(x[0], fc, xre, xim, tau);
+            FHE_STAMP(1);    // convert + twist + stage 1 (2 passes, 1 swap transpose, 8 LDS writes)
+            wave_local_fence();
+            swap10_fwd_stage2(x[0], fc, xre, xim, tau);
+            FHE_STAMP(2);    // stage 2 (8 LDS reads, 2 passes, 1 swap transpose)
+            wave_local_fence();
+            swap10_fwd_stage3(x[0], fc, xre, xim, tau);
+            FHE_STAMP(3);    // stage 3 (twiddle + 8 LDS writes)
+#else
             swap10_forward_head(x[0], fc, xre, xim, tau);
+#endif
             __syncthreads();
+            FHE_STAMP(4);    // barrier 1 (forward hand-over)
 #pragma unroll
             for (int r = 0; r < K1; r++) {
                 const int row = (g + r) % K1;                    // r = 0: own polynomial
@@ -339,9 +452,13 @@ blind_rotate_kernel(BlindRotateArgs args) {
             // forward planes
             double* fre = lds_f + (size_t)g * CFG::GROUP_SLOTS;
             double* fim = fre + CFG::PLANE;
+            FHE_STAMP(5);    // 16 LDS reads + last pass on both polynomials + key wait + multiply-accumulate
             swap10_inverse_head(outf, fre, fim, tau);
+            FHE_STAMP(6);    // inverse first pass + 8 LDS writes
             __syncthreads();
+            FHE_STAMP(7);    // barrier 2 (inverse hand-over)
             swap10_inverse_tail(outf, fc, fre, fim, tau);
+            FHE_STAMP(8);    // inverse passes 2-5 (two LDS round trips, two swap transposes)
         } else {
 #pragma unroll
         for (int it = 0; it < L; it++) {
@@ -349,9 +466,10 @@ blind_rotate_kernel(BlindRotateArgs args) {
             cplx x[R];
 #pragma unroll
             for (int m = 0; m < R; m++) {
+                if (L == 1) { x[m] = digit_point(st_lo[m], st_hi[m], twist[m], twbias[m]); continue; }
                 cplx z;
-                z.re = (double)(L == 1 ? (int32_t)st_lo[m] : decomp_next_digit(st_lo[m], args.base_log));
-                z.im = (double)(L == 1 ? (int32_t)st_hi[m] : decomp_next_digit(st_hi[m], args.base_log));
+                z.re = (double)decomp_next_digit(st_lo[m], args.base_log);
+                z.im = (double)decomp_next_digit(st_hi[m], args.base_log);
                 x[m] = cmul(z, twist[m]);                        // fft/mod.rs:220-239
             }
             fft_forward<PL>(x, fc, xre, xim, tau);
@@ -410,7 +528,13 @@ blind_rotate_kernel(BlindRotateArgs args) {
             FHE_PIN_ORDER();      // next point's conversions overlap this point's LDS writes
         }
         __syncthreads();
+        FHE_STAMP(9);    // untwist + torus rounding + accumulate + 8 LDS writes + barrier 3
     }
+#ifdef FHESTR_STAMPS
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)
+        for (int sg = 0; sg < STAMP_SEGS; sg++)
+            g_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * STAMP_SEGS + sg] = stamp_acc[sg];
+#endif
 
     // sample extraction at degree 0 (glwe_sample_extraction.rs:121-146)
     uint64_t* out = args.lwe_out + (size_t)sample * ((size_t)(K1 - 1) * N + 1);
@@ -468,7 +592,10 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
     const uint32_t n = args.n;
     const uint64_t* lwe = args.lwe_small + (size_t)sample * (n + 1);
     const uint64_t* lut = args.luts + (size_t)(args.lut_idx ? args.lut_idx[sample] : 0) * K1 * N;
+    const uint32_t acc_address = lds_address(lds_acc);     // 8N-aligned, see blind_rotate_kernel
+    if (PL::SWAP && (acc_address & (8u * N - 1u))) __builtin_trap();
     const uint32_t bL = args.base_log * L;
+    const uint32_t dbias = decomp_bias_constant(bL <= 31 ? bL : 31);
 
     for (uint32_t i = threadIdx.x; i < n; i += CFG::THREADS) {
         const uint64_t a = lwe[i];
@@ -477,12 +604,15 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
 
     FftConsts<PL> fc;
     fft_init_consts<PL>(fc, tau);
-    cplx twist[R];
+    cplx twist[R], twbias[R];
 #pragma unroll
     for (int m = 0; m < R; m++) {
         double sn, cs;
         sincospi((double)PL::point(tau, m) / (double)N, &sn, &cs);
         twist[m].re = cs; twist[m].im = sn;
+        const double cb = -(double)((1u << (args.base_log * L - 1)) - 1u);
+        twbias[m].re = cb * (cs - sn);
+        twbias[m].im = cb * (cs + sn);
     }
 
     uint64_t acc_lo[K1][R], acc_hi[K1][R];
@@ -509,40 +639,58 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
 
     const double2* fbsk = reinterpret_cast<const double2*>(args.fbsk);
     constexpr size_t GGSW_ELEMS = (size_t)L * K1 * K1 * P;
+    const uint32_t key_off = (uint32_t)tau * 16u;
+    const auto key_rsrc = key_resource(args.fbsk, (size_t)n * GGSW_ELEMS * 16);
 
     uint32_t d_next = lds_d[0];
     for (uint32_t i = 0; i < n; i++) {
-        const uint32_t d = d_next;
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)d_next);   // workgroup-uniform: scalar
         d_next = lds_d[i + 1 < n ? i + 1 : i];
         if (d == 0xFFFFFFFFu) continue;
         const Rotation<PL, LOGN> rot(d, tau);
         const double2* bk0 = fbsk + (size_t)i * GGSW_ELEMS;
 
+        // key rows by buffer loads: scalar row offset + one per-thread byte offset (see blind_rotate_kernel)
         double2 bpre[CFG::PREFETCH_ALL ? K1 : 1][CFG::PREFETCH_ALL ? K1 : 1][R];
         if (CFG::PREFETCH_ALL) {
-            const double2* bk = bk0 + (size_t)(L - 1) * K1 * K1 * P;
 #pragma unroll
             for (int row = 0; row < K1; row++)
 #pragma unroll
                 for (int col = 0; col < K1; col++)
 #pragma unroll
                     for (int rho = 0; rho < R; rho++)
-                        bpre[row][col][rho] = bk[((size_t)row * K1 + col) * P + rho * T + tau];
+                        bpre[row][col][rho] = key_load(key_rsrc, key_off,
+                            (uint32_t)((i * GGSW_ELEMS + (size_t)(L - 1) * K1 * K1 * P + ((size_t)row * K1 + col) * P + rho * T) * 16));
         }
 
         uint32_t st_lo[K1][R], st_hi[K1][R];
+        uint32_t row_base[K1];
+#pragma unroll
+        for (int p = 0; p < K1; p++) {
+            row_base[p] = (acc_address + (uint32_t)p * 8u * N) | rot.rbits8;
+            if constexpr (PL::SWAP) asm volatile("" : "+s"(row_base[p]));
+        }
 #pragma unroll
         for (int p = 0; p < K1; p++)
 #pragma unroll
             for (int m = 0; m < R; m++)
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    uint32_t slot, sm32;
-                    rot.source(tau, m, h, slot, sm32);
+                    uint32_t sm32;
+                    uint64_t gathered;
+                    if constexpr (PL::SWAP) {
+                        uint32_t address;
+                        rot.source_bytes(m, h, row_base[p], address, sm32);
+                        gathered = lds_load_u64(address);
+                    } else {
+                        uint32_t slot;
+                        rot.source(tau, m, h, slot, sm32);
+                        gathered = lds_acc[(size_t)p * N + slot];
+                    }
                     const uint64_t sm = ((uint64_t)sm32 << 32) | sm32;
-                    const uint64_t v = (lds_acc[(size_t)p * N + slot] ^ sm) - sm;
+                    const uint64_t v = (gathered ^ sm) - sm;
                     const uint64_t own = h == 0 ? acc_lo[p][m] : acc_hi[p][m];
-                    const uint32_t st = L == 1 ? (uint32_t)decomp_single_digit(v - own, bL) : decomp_init_state(v - own, bL);
+                    const uint32_t st = L == 1 ? decomp_single_biased(v - own, bL, dbias) : decomp_init_state(v - own, bL);
                     if (h == 0) st_lo[p][m] = st; else st_hi[p][m] = st;
                 }
 
@@ -555,9 +703,10 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
             for (int p = 0; p < K1; p++)
 #pragma unroll
                 for (int m = 0; m < R; m++) {
+                    if (L == 1) { x[p][m] = digit_point(st_lo[p][m], st_hi[p][m], twist[m], twbias[m]); continue; }
                     cplx z;
-                    z.re = (double)(L == 1 ? (int32_t)st_lo[p][m] : decomp_next_digit(st_lo[p][m], args.base_log));
-                    z.im = (double)(L == 1 ? (int32_t)st_hi[p][m] : decomp_next_digit(st_hi[p][m], args.base_log));
+                    z.re = (double)decomp_next_digit(st_lo[p][m], args.base_log);
+                    z.im = (double)decomp_next_digit(st_hi[p][m], args.base_log);
                     x[p][m] = cmul(z, twist[m]);
                 }
             fft_forward_multi<PL, K1>(x, fc, lds_x, CFG::GROUP_SLOTS, CFG::PLANE, tau);

@@ -147,8 +147,8 @@ blind_rotate_multibit_kernel(BlindRotateArgs args) {
         // ---- external product acc <- GGSW (x) acc (ggsw.rs:477-598 on a zeroed destination) ----
         cplx x[K1][R];
 #pragma unroll
-        for (int m = 0; m < R; m++) {
-            cplx z;
+        for (int m = 0; m < R; m++) {     // (the biased two-instruction digit of the classic kernels would cost this
+            cplx z;                       //  kernel 16 more VGPRs for its constants: the prefetched GGSWs need them)
             z.re = (double)decomp_single_digit(acc_lo[m], bL);
             z.im = (double)decomp_single_digit(acc_hi[m], bL);
             x[0][m] = cmul(z, twist[m]);

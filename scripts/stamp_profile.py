@@ -1,0 +1,41 @@
+"""Where one CMUX step of blind_rotate_kernel spends its cycles (diagnostic -DFHESTR_STAMPS build):
+
+    hipcc ... -DFHESTR_STAMPS -o build/ab/libfhestr_stamps.so ...    ("stamps")
+    FHESTR_LIB=build/ab/libfhestr_stamps.so python3 scripts/stamp_profile.py
+
+Prints, per segment, the average cycles per step and wave and its share.  The stamps' fences forbid the
+overlaps the real kernel has, so only the shares mean something."""
+import ctypes as C
+import sys
+
+import numpy as np
+
+sys.path.insert(0, "fhe-string-bounty_amd")
+import fhestr
+
+SEGS = ["gather+decompose (incl. key-load issue)", "cvt+twist+fwd stage1 (2 passes, swap, 8 wr)", "fwd stage2 (8 rd, 2 passes, swap)",
+        "fwd stage3 (twiddle, 8 wr)", "barrier 1", "fwd tail x2 (16 rd) + key wait + MAC", "inv head (pass, 8 wr)", "barrier 2",
+        "inv tail (2 round trips, 2 swaps, 4 passes)", "untwist+round+acc+8 wr+barrier 3"]
+P = fhestr.PARAM_MESSAGE_2_CARRY_2_KS_PBS
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+ck = fhestr.ClientKey(P, 7)
+g, s = ck.secret_keys()
+eng = fhestr.Engine(P, 0)
+eng.generate_keys(g, s, 7)
+lut, _ = eng.generate_lookup_table(lambda x: x)
+rng = np.random.default_rng(0)
+msgs = rng.integers(0, 16, size=B)
+cts = ck.encrypt(msgs)
+for _ in range(3):
+    out = eng.apply_lookup_table(cts, np.full(B, lut, dtype=np.uint32))
+print("correct:", np.array_equal(ck.decrypt(out), msgs), "kernel ms", eng.last_kernel_ms())
+n = B * 8 * len(SEGS)
+buf = np.zeros(n, dtype=np.uint64)
+L = fhestr.lib()
+L.fhe_debug_read_stamps.argtypes = [C.c_void_p, C.c_size_t]
+assert L.fhe_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), n) == 0
+st = buf.reshape(B, 8, len(SEGS)).astype(np.float64) / P.n     # cycles per step (s_memtime: shader clock... 100 MHz ticks?)
+tot = st.sum(axis=2).mean()
+print(f"sum of segments: {tot:.0f} ticks per step and wave")
+for i, name in enumerate(SEGS):
+    print(f"  {i}: {st[:, :, i].mean():8.1f}  {100 * st[:, :, i].mean() / tot:5.1f} %   (waves 0-3 {st[:, :4, i].mean():7.1f}, waves 4-7 {st[:, 4:, i].mean():7.1f})  {name}")
