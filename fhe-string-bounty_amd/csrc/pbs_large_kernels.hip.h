@@ -264,12 +264,15 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
     const double2* fbsk = reinterpret_cast<const double2*>(args.fbsk);
     constexpr size_t GGSW_ELEMS = (size_t)L * K1 * K1 * P;
 
+    FHE_STAMP_DECL;
+    FHE_STAMP(-1);
     for (uint32_t i = 0; i < n; i++) {
         if (tid == 0) {
             const uint64_t a = lwe[i];
             s_d = a == 0 ? 0xFFFFFFFFu : modulus_switch(a, LOGN);
         }
         __syncthreads();
+        FHE_STAMP(0);    // step head (mask element broadcast)
         const uint32_t d = s_d;
         if (d == 0xFFFFFFFFu) { __syncthreads(); continue; }
         const uint32_t rem = d & (N - 1);
@@ -335,7 +338,9 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
                 }
             }
         }
+        FHE_STAMP(1);    // phase 1 (this wave's share)
         __syncthreads();
+        FHE_STAMP(2);    // wait for the slowest wave of phase 1
 
         // ---- phase 2: row transforms, multiply-accumulate with the GGSW, inverse row transforms -> tmp2 ----
         const double2* bk0 = fbsk + (size_t)i * GGSW_ELEMS;
@@ -397,7 +402,9 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
                 }
             }
         }
+        FHE_STAMP(3);    // phase 2
         __syncthreads();
+        FHE_STAMP(4);    // barrier after phase 2
 
         // ---- phase 3: inverse column transforms, untwist, torus rounding, accumulate ----
         for (int p = 0; p < K1; p++) {
@@ -429,8 +436,15 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
                 }
             }
         }
+        FHE_STAMP(5);    // phase 3
         __syncthreads();
+        FHE_STAMP(6);    // barrier after phase 3
     }
+#ifdef FHESTR_STAMPS
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)
+        for (int sg = 0; sg < STAMP_SEGS; sg++)
+            g_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * STAMP_SEGS + sg] = stamp_acc[sg];
+#endif
 
     // sample extraction at degree 0 (glwe_sample_extraction.rs:121-146)
     uint64_t* out = args.lwe_out + (size_t)sample * ((size_t)(K1 - 1) * N + 1);

@@ -16,17 +16,21 @@ import fhestr
 SEGS = ["gather+decompose (incl. key-load issue)", "cvt+twist+fwd stage1 (2 passes, swap, 8 wr)", "fwd stage2 (8 rd, 2 passes, swap)",
         "fwd stage3 (twiddle, 8 wr)", "barrier 1", "fwd tail x2 (16 rd) + key wait + MAC", "inv head (pass, 8 wr)", "barrier 2",
         "inv tail (2 round trips, 2 swaps, 4 passes)", "untwist+round+acc+8 wr+barrier 3"]
-P = fhestr.PARAM_MESSAGE_2_CARRY_2_KS_PBS
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+P = fhestr.PARAM_MESSAGE_2_CARRY_2_KS_PBS
+if len(sys.argv) > 2 and sys.argv[2] == "p44":      # the large-N kernel: phases of one CMUX step
+    P = fhestr.PARAM_MESSAGE_4_CARRY_4_KS_PBS
+    SEGS = ["step head", "phase 1: decompose + column transforms -> tmp", "barrier 1", "phase 2: rows, multiply-accumulate, inverse rows -> tmp2",
+            "barrier 2", "phase 3: inverse columns, accumulate", "barrier 3", "-", "-", "-"]
 ck = fhestr.ClientKey(P, 7)
 g, s = ck.secret_keys()
 eng = fhestr.Engine(P, 0)
 eng.generate_keys(g, s, 7)
 lut, _ = eng.generate_lookup_table(lambda x: x)
 rng = np.random.default_rng(0)
-msgs = rng.integers(0, 16, size=B)
+msgs = rng.integers(0, P.msg_mod * P.carry_mod, size=B)
 cts = ck.encrypt(msgs)
-for _ in range(3):
+for _ in range(1 if P.N > 4096 else 3):
     out = eng.apply_lookup_table(cts, np.full(B, lut, dtype=np.uint32))
 print("correct:", np.array_equal(ck.decrypt(out), msgs), "kernel ms", eng.last_kernel_ms())
 n = B * 8 * len(SEGS)
