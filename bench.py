@@ -87,26 +87,48 @@ def bench_strings(fhestr, eng, ck, P, rank, world, local_rank, reps=3):
     off = int(rng.integers(0, 240))
     pat = hay[off: off + 16]
     enc = lambda s, cap: ck.encrypt(fhestr.string_to_blocks(P, s, cap))
+    differ = bytearray(hay)
+    differ[int(rng.integers(0, 256))] ^= 1
+    differ = bytes(differ)
+    text = bytes(rng.choice(np.frombuffer(b"The quick brown fox jumps over the lazy dog and the cat", dtype=np.uint8), size=1000))
+    text = text.replace(b"the ", b"xyz ") + b" the end of the line"
+    bit = lambda want: (lambda d: int(d[0]) == want)
+    index = lambda want: (lambda d: int(d[0]) == 1 and sum(int(v) * P.msg_mod ** i for i, v in enumerate(d[1:])) == want)
+    chars = lambda want, cap: (lambda d: fhestr.blocks_to_string(P, d)[:cap].rstrip(b"\0") == want)
+    # (op, a_cap, b_cap, clear pattern, encrypted inputs, check of the decrypted outputs, timed repetitions)
     cases = {
-        "eq_256_enc_enc": ("eq", 256, 256, np.concatenate([enc(hay, 256), enc(hay, 256)]), 1),
-        "contains_16_in_256_enc_enc": ("contains", 256, 16, np.concatenate([enc(hay, 256), enc(pat, 16)]), 1),
+        # config 3: eq / ne on 256-char strings, pattern encrypted and clear, equal and differing in one position
+        "eq_256_enc_enc": ("eq", 256, 256, None, np.concatenate([enc(hay, 256), enc(hay, 256)]), bit(1), reps),
+        "eq_256_enc_enc_differ": ("eq", 256, 256, None, np.concatenate([enc(hay, 256), enc(differ, 256)]), bit(0), 1),
+        "ne_256_enc_enc": ("ne", 256, 256, None, np.concatenate([enc(hay, 256), enc(differ, 256)]), bit(1), reps),
+        "eq_256_enc_clear": ("eq_clear", 256, 0, hay, enc(hay, 256), bit(1), reps),
+        "ne_256_enc_clear": ("ne_clear", 256, 0, differ, enc(hay, 256), bit(1), reps),
+        # config 4: 16-char encrypted pattern in a 256-char haystack
+        "contains_16_in_256_enc_enc": ("contains", 256, 16, None, np.concatenate([enc(hay, 256), enc(pat, 16)]), bit(1), reps),
+        "contains_16_in_256_enc_enc_absent": ("contains", 256, 16, None,
+                                              np.concatenate([enc(hay, 256), enc(b"0123456789ABCDEF", 16)]), bit(0), 1),
+        "find_16_in_256_enc_enc": ("find", 256, 16, None, np.concatenate([enc(hay, 256), enc(pat, 16)]), index(hay.find(pat)), 2),
+        # config 5 on this parameter set (N = 2048; the N = 32768 run is the "p44" section)
+        "to_lower_1024": ("to_lower", 1024, 0, None, enc(text, 1024), chars(text.lower(), 1024), 2),
+        "replace_clear_4_in_1024": ("replace_clear", 1024, 0, b"the THAT", enc(text, 1024),
+                                    chars(text.replace(b"the ", b"THAT"), 1024), 2),
     }
     out = {}
     dev = torch.device("cuda", local_rank)
-    for name, (op, a_cap, b_cap, inputs, want) in cases.items():
-        plan = fhestr.Plan.string_op(eng, op, a_cap, b_cap, world=world)
+    for name, (op, a_cap, b_cap, clear, inputs, check, n_rep) in cases.items():
+        plan = fhestr.Plan.string_op(eng, op, a_cap, b_cap, clear=clear, world=world)
         runner = ShardedPlanRunner(plan, rank, world, GpuBackend(plan, dev))
         res = runner.run(inputs)   # warm-up + correctness
-        ok = int(ck.decrypt(res)[0]) == want
+        ok = bool(check(ck.decrypt(res)))
         d_inputs = torch.from_numpy(inputs.view(np.int64)).to(dev)
         timings = {}
         for label, src in (("resident", d_inputs), ("from_host", inputs)):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(reps):
+            for _ in range(n_rep):
                 runner.run(src)
             torch.cuda.synchronize()
-            timings[label] = (time.perf_counter() - t0) / reps * 1e3
+            timings[label] = (time.perf_counter() - t0) / n_rep * 1e3
         ms = timings["resident"]
         info = plan.info()
         out[name] = {"ms_per_op": ms, "ms_per_op_inputs_from_host": timings["from_host"], "n_pbs": info["n_pbs"],
