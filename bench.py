@@ -144,41 +144,61 @@ def bench_strings(fhestr, eng, ck, P, rank, world, local_rank, reps=3):
 
 
 def bench_multi_bit(fhestr, local_rank, B, steps):
-    """Same 256-LWE step with the multi-bit PBS (PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS,
-    lwe_multi_bit_programmable_bootstrapping.rs): a different parameter set of the reference, reported
-    next to the headline, never as the headline.  Keys are generated on the device."""
+    """Same 256-LWE step with the multi-bit PBS (PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_{2,3}_KS_PBS,
+    lwe_multi_bit_programmable_bootstrapping.rs): different parameter sets of the reference, reported
+    next to the headline, never as the headline.  Keys are generated on the device.  Also the small-batch
+    latency (1 and 32 LWEs: the groups' GGSWs are prepared on the whole GPU first, fhe_engine_set_multibit_combine_max)
+    and FheString::eq on 256-char strings, which is what the shorter serial chain is for."""
     import torch
-    P = fhestr.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS
-    M = P.msg_mod * P.carry_mod
-    ck = fhestr.ClientKey(P, SEED + 1)
-    g, s = ck.secret_keys()
-    eng = fhestr.Engine(P, local_rank)
-    try:
-        eng.generate_keys(g, s, SEED + 1)
-        rng = np.random.default_rng(SEED + 1)
-        table = rng.integers(0, M, size=M)
-        lut, _ = eng.generate_lookup_table(lambda x: int(table[x]))
-        msgs = rng.integers(0, M, size=B)
-        d_in = torch.from_numpy(ck.encrypt(msgs).view(np.int64)).cuda()
-        d_idx = torch.full((B,), int(lut), dtype=torch.int32, device="cuda")
-        d_out = torch.zeros_like(d_in)
-        torch.cuda.synchronize()
-        for _ in range(3):
-            eng.apply_lookup_table_dev(d_in.data_ptr(), d_idx.data_ptr(), d_out.data_ptr(), B)
-        eng.synchronize()
-        eng.kernel_times(reset=True)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            eng.apply_lookup_table_dev(d_in.data_ptr(), d_idx.data_ptr(), d_out.data_ptr(), B)
-        eng.synchronize()
-        dt = time.perf_counter() - t0
-        ks_ms, br_ms, calls = eng.kernel_times(reset=True)
-        ok = bool(np.array_equal(ck.decrypt(d_out.cpu().numpy().view(np.uint64)), table[msgs]))
-        return {"params": P.name, "grouping_factor": P.grouping, "batch": B, "pbs_per_s": B * steps / dt,
-                "ms_per_step": dt / steps * 1e3, "kernel_ms": {"keyswitch": ks_ms / max(calls, 1), "blind_rotate": br_ms / max(calls, 1)},
-                "verified_decrypt": ok}
-    finally:
-        eng.close()
+    out = {}
+    for P in (fhestr.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS, fhestr.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS):
+        M = P.msg_mod * P.carry_mod
+        ck = fhestr.ClientKey(P, SEED + 1)
+        g, s = ck.secret_keys()
+        eng = fhestr.Engine(P, local_rank)
+        try:
+            eng.generate_keys(g, s, SEED + 1)
+            rng = np.random.default_rng(SEED + 1)
+            table = rng.integers(0, M, size=M)
+            lut, _ = eng.generate_lookup_table(lambda x: int(table[x]))
+            rec = {"params": P.name, "grouping_factor": P.grouping}
+            for nb in (B, 32, 1):
+                msgs = rng.integers(0, M, size=nb)
+                d_in = torch.from_numpy(ck.encrypt(msgs).view(np.int64)).cuda()
+                d_idx = torch.full((nb,), int(lut), dtype=torch.int32, device="cuda")
+                d_out = torch.zeros_like(d_in)
+                torch.cuda.synchronize()
+                for _ in range(3):
+                    eng.apply_lookup_table_dev(d_in.data_ptr(), d_idx.data_ptr(), d_out.data_ptr(), nb)
+                eng.synchronize()
+                eng.kernel_times(reset=True)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    eng.apply_lookup_table_dev(d_in.data_ptr(), d_idx.data_ptr(), d_out.data_ptr(), nb)
+                eng.synchronize()
+                dt = time.perf_counter() - t0
+                ks_ms, br_ms, calls = eng.kernel_times(reset=True)
+                ok = bool(np.array_equal(ck.decrypt(d_out.cpu().numpy().view(np.uint64)), table[msgs]))
+                r = {"batch": nb, "pbs_per_s": nb * steps / dt, "ms_per_step": dt / steps * 1e3,
+                     "kernel_ms": {"keyswitch": ks_ms / max(calls, 1), "blind_rotate": br_ms / max(calls, 1)},
+                     "verified_decrypt": ok}
+                if nb == B:
+                    rec.update(r)
+                else:
+                    rec[f"batch_{nb}"] = r
+            ops = fhestr.FheStringOps(eng)
+            text = bytes(rng.integers(0x61, 0x7B, size=256, dtype=np.uint8))
+            ea, eb = (ck.encrypt(fhestr.string_to_blocks(P, text, 256)) for _ in range(2))
+            bit = ops.eq(ea, eb)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ops.eq(ea, eb)
+            rec["fhestring_eq_256_ms"] = (time.perf_counter() - t0) / 3 * 1e3     # host buffers in and out
+            rec["fhestring_eq_256_correct"] = int(ck.decrypt(np.asarray(bit).reshape(1, -1))[0]) == 1
+            out[f"group_{P.grouping}"] = rec
+        finally:
+            eng.close()
+    return out
 
 
 def flop_per_cmux_step(P):

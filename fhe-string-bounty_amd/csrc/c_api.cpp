@@ -85,6 +85,15 @@ int fhe_engine_set_variant(fhe_engine* eng, int log2_points) {
     API_END
 }
 
+int fhe_engine_set_multibit_combine_max(fhe_engine* eng, uint32_t max_batch) {
+    API_BEGIN
+    CHECK_PTR(eng);
+    if (max_batch > 1024) return fhe::fail("multibit_combine_max: at most 1024 (workspace grows by 16 MB per LWE at N = 2048)");
+    eng->impl->multibit_combine_max = max_batch;
+    return 0;
+    API_END
+}
+
 int fhe_lut_generate(fhe_engine* eng, const uint64_t* table, uint32_t* lut_id, uint64_t* degree) {
     API_BEGIN
     CHECK_PTR(eng); CHECK_PTR(table); CHECK_PTR(lut_id);

@@ -47,6 +47,7 @@ struct Engine {
     const BrVariant* variant = nullptr;       // layout used up to one LWE per CU
     const BrVariant* variant_large = nullptr; // same Fourier-key layout, used for larger batches (may equal variant)
     int cu_count = 256;
+    uint32_t multibit_combine_max = 64;       // multi-bit PBS: batches up to this size prepare their GGSWs on the whole GPU first
 
     // resident keys / tables
     uint64_t* d_ksk = nullptr;       // reference layout (kept only when the byte-plane path is disabled)

@@ -8,6 +8,7 @@
 // memset -> keyswitch_kernel -> blind_rotate_kernel.
 #include "engine.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -50,6 +51,13 @@ struct BrVariant {
     size_t convert_lds;
     const void* rotate_fn;
     const void* convert_fn;
+    // multi-bit, small batches: build every (LWE, group) GGSW on the whole GPU first, then rotate against them
+    const void* combine_fn = nullptr;
+    const void* rotate_combined_fn = nullptr;
+    size_t combine_lds = 0;
+    int combine_grid_y = 1;
+    int combine_chunk = 1;
+    size_t combined_bytes = 0;    // one combined GGSW
 };
 
 template <int LOGN, int LOGR, int K1, int L>
@@ -102,6 +110,12 @@ BrVariant make_multibit_variant() {
     v.lds_bytes = CFG::LDS_FIXED;
     v.lds_per_n = 4 * ((1 << G) - 1) / G + 4;         // (n/G) * (2^G - 1) degrees, rounded up
     v.rotate_fn = reinterpret_cast<const void*>(&blind_rotate_multibit_kernel<LOGN, LOGR, K1, G>);
+    v.combine_fn = reinterpret_cast<const void*>(&multibit_combine_kernel<LOGN, LOGR, K1, G>);
+    v.rotate_combined_fn = reinterpret_cast<const void*>(&blind_rotate_multibit_kernel<LOGN, LOGR, K1, G, true>);
+    v.combine_lds = CFG::LDS_ROOTS;
+    v.combine_grid_y = CFG::R / CFG::COMBINE_SLOTS;
+    v.combine_chunk = CFG::COMBINE_CHUNK;
+    v.combined_bytes = (size_t)K1 * K1 * CFG::P * 16;
     return v;
 }
 
@@ -172,6 +186,7 @@ int Engine::create(const fhe_params_t& p, int device, Engine** out) {
     e->device = device;
     e->variant = v;
     e->variant_large = v;
+    if (const char* m = getenv("FHESTR_MULTIBIT_COMBINE_MAX")) e->multibit_combine_max = (uint32_t)std::min(1024, std::max(0, atoi(m)));
     if (env_logr == 0) {   // automatic: "wide" twin (same points per thread => same key layout) for big batches
         const BrVariant* w = find_variant(p, v->logR | 16);
         if (w) e->variant_large = w;
@@ -239,6 +254,9 @@ int Engine::set_variant(int logR) {
                                     (int)(variant->lds_bytes + (size_t)p.n * variant->lds_per_n)));
         HIP_TRY(hipFuncSetAttribute(variant_large->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(variant_large->lds_bytes + (size_t)p.n * variant_large->lds_per_n)));
+        if (variant->rotate_combined_fn)
+            HIP_TRY(hipFuncSetAttribute(variant->rotate_combined_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(variant->lds_bytes + (size_t)p.n * variant->lds_per_n)));
     }
     return 0;
 }
@@ -355,6 +373,9 @@ int Engine::install_keys(uint64_t* d_ksk_std, uint64_t* d_std) {
                                 (int)(variant->lds_bytes + (size_t)p.n * variant->lds_per_n)));
     HIP_TRY(hipFuncSetAttribute(variant_large->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(variant_large->lds_bytes + (size_t)p.n * variant_large->lds_per_n)));
+    if (variant->rotate_combined_fn)
+        HIP_TRY(hipFuncSetAttribute(variant->rotate_combined_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(variant->lds_bytes + (size_t)p.n * variant->lds_per_n)));
     return 0;
 }
 
@@ -447,6 +468,23 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
     // one LWE per CU or fewer: spread it over more threads; above that: the compact layout that
     // lets two LWEs share a CU
     const BrVariant* v = count > (uint32_t)cu_count ? variant_large : variant;
+    if (v->combine_fn && count <= multibit_combine_max) {
+        // far fewer LWEs than CUs: the idle CUs prepare the groups' GGSWs (lwe_multi_bit_programmable_bootstrapping.rs
+        // splits the same way over CPU threads), the rotation then runs n/G plain external products
+        const size_t groups = p.n / p.grouping_factor;
+        if (ensure(&d_ws, &cap_ws, (size_t)count * groups * v->combined_bytes)) return 1;
+        MultiBitCombineArgs ca{a, reinterpret_cast<double2*>(d_ws)};
+        void* cargs[] = {(void*)&ca};
+        HIP_TRY(hipLaunchKernel(v->combine_fn, dim3((unsigned)groups, (unsigned)v->combine_grid_y, (count + v->combine_chunk - 1) / v->combine_chunk),
+                                dim3(v->threads), cargs,
+                                v->combine_lds, stream));
+        BlindRotateArgs b = a;
+        b.fbsk = reinterpret_cast<const double*>(d_ws);
+        void* bargs[] = {(void*)&b};
+        HIP_TRY(hipLaunchKernel(v->rotate_combined_fn, dim3(count), dim3(v->threads), bargs,
+                                v->lds_bytes + (size_t)p.n * v->lds_per_n, stream));
+        return 0;
+    }
     if (v->large) {
         if (ensure(&d_ws, &cap_ws, (size_t)count * v->ws_bytes)) return 1;
         BlindRotateLargeArgs la{a, reinterpret_cast<unsigned char*>(d_ws)};

@@ -19,6 +19,13 @@
 //     n/G steps instead of n.
 // Thread layout, FFT plan and Fourier-key slot order are those of blind_rotate_kernel with the
 // FftSwap10 plan (pbs_kernels.hip.h); the key is converted by the same bsk_convert_kernel.
+//
+// Small batches (far fewer LWEs than CUs) split the step the way the reference does, over CUs instead
+// of CPU threads: multibit_combine_kernel builds every (LWE, group) GGSW on the whole GPU first (one
+// workgroup per group and slot half keeps the group's 2^G key GGSWs in registers and walks the batch),
+// then blind_rotate_multibit_kernel<..., PRE = true> runs n/G plain external products against its own
+// LWE's combined GGSWs (64 KB per step, prefetched like the classic kernel's key).  Same operations in the
+// same order as the fused step, so both paths give bit-identical ciphertexts.
 #pragma once
 #include "pbs_kernels.hip.h"
 
@@ -31,6 +38,9 @@ struct BrMultiBitCfg {
     static constexpr int N = Base::N, P = Base::P, R = Base::R, T = Base::T;
     static constexpr int THREADS = Base::THREADS;
     static constexpr int SEL = (1 << G) - 1;                   // monomial-carrying GGSWs per group
+    // register slots of every GGSW one combine workgroup keeps: 2^G * K1 * SLOTS c64 <= 128 VGPRs
+    static constexpr int COMBINE_CHUNK = 8;    // LWEs one combine workgroup walks with the key GGSWs in registers
+    static constexpr int COMBINE_SLOTS = (SEL + 1) * K1 * R * 4 <= 128 ? R : ((SEL + 1) * K1 * R * 2 <= 128 ? R / 2 : R / 4);
     static constexpr int ROOT_LO_BITS = (LOGN + 1) / 2, ROOT_HI_BITS = LOGN + 1 - ROOT_LO_BITS;
     // LDS: forward planes + inverse planes (as the classic split kernel) + two-level root table of
     // e^{i pi m / N}, m < 2N; the per-group monomial degrees ((n/G) * SEL u32) follow dynamically
@@ -38,7 +48,121 @@ struct BrMultiBitCfg {
     static constexpr size_t LDS_FIXED = 2 * (size_t)K1 * Base::GROUP_SLOTS * 8 + LDS_ROOTS;
 };
 
+// frequency of register slot 0 of thread tau (FftSwap10: regs k4 | wave k3 | lane(5,4) k2 | lane(3,2) k0 |
+// lane(1,0) k1, f = k0 + 4 k1 + 16 k2 + 64 k3 + 256 k4), as 1 - 4 f mod 2N: the monomial X^d has the value
+// w^{d (1 - 4 f)} at that slot, w = e^{i pi / N}
+template <int N>
+__device__ __forceinline__ uint32_t multibit_slot_exponent(int tau) {
+    const int lane = tau & 63, wv = tau >> 6;
+    const uint32_t f_tau = ((lane >> 2) & 3) + 4 * (lane & 3) + 16 * (lane >> 4) + 64 * wv;
+    return (1u - 4u * f_tau) & (2u * N - 1u);
+}
+
+// e^{i pi m / N} = root_lo[m & mask] * root_hi[m >> ROOT_LO_BITS], m < 2N
+template <class CFG>
+__device__ __forceinline__ void multibit_fill_roots(double2* root_lo, double2* root_hi) {
+    for (int e = threadIdx.x; e < (1 << CFG::ROOT_LO_BITS); e += CFG::THREADS) {
+        double sn, cs;
+        sincospi((double)e / (double)CFG::N, &sn, &cs);
+        root_lo[e] = make_double2(cs, sn);
+    }
+    for (int e = threadIdx.x; e < (1 << CFG::ROOT_HI_BITS); e += CFG::THREADS) {
+        double sn, cs;
+        sincospi((double)((size_t)e << CFG::ROOT_LO_BITS) / (double)CFG::N, &sn, &cs);
+        root_hi[e] = make_double2(cs, sn);
+    }
+}
+
+// value of X^d at slot 0 of a thread with slot exponent c_tau, and the quarter turn (-i)^d that leads from
+// one register slot to the next
+template <class CFG>
+__device__ __forceinline__ void multibit_monomial(uint32_t d, uint32_t c_tau, const double2* root_lo,
+                                                  const double2* root_hi, cplx& mono, cplx& turn) {
+    const uint32_t mi = (d * c_tau) & (2u * CFG::N - 1u);
+    const double2 a = root_lo[mi & ((1u << CFG::ROOT_LO_BITS) - 1u)], b = root_hi[mi >> CFG::ROOT_LO_BITS];
+    mono.re = a.x * b.x - a.y * b.y;
+    mono.im = a.x * b.y + a.y * b.x;
+    const int q = d & 3;
+    turn.re = q == 0 ? 1.0 : q == 2 ? -1.0 : 0.0;
+    turn.im = q == 1 ? -1.0 : q == 3 ? 1.0 : 0.0;
+}
+
+struct MultiBitCombineArgs {
+    BlindRotateArgs a;
+    double2* combined;      // [count][n/G][K1][K1][P] c64, slot order of the Fourier key
+};
+
+// prepare_multi_bit_ggsw (:18-83) for a whole batch: grid (n/G, R / SLOTS, ceil(batch / COMBINE_CHUNK)); the
+// workgroup keeps the group's 2^G GGSWs (its SLOTS register slots of them) in VGPRs and writes
+// G0 + sum_sel G_sel * X^{d_sel} for its chunk of the batch's LWEs.
 template <int LOGN, int LOGR, int K1, int G>
+__global__ void __launch_bounds__((BrMultiBitCfg<LOGN, LOGR, K1, G>::THREADS))
+multibit_combine_kernel(MultiBitCombineArgs ca) {
+    using CFG = BrMultiBitCfg<LOGN, LOGR, K1, G>;
+    constexpr int N = CFG::N, P = CFG::P, T = CFG::T, SEL = CFG::SEL, SLOTS = CFG::COMBINE_SLOTS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* root_lo = reinterpret_cast<double2*>(smem);
+    double2* root_hi = root_lo + (1 << CFG::ROOT_LO_BITS);
+    const BlindRotateArgs& args = ca.a;
+    const int g = threadIdx.x / T, tau = threadIdx.x % T;
+    const uint32_t grp = blockIdx.x, rho0 = blockIdx.y * SLOTS;
+    const uint32_t n = args.n, groups = n / G;
+    constexpr size_t GGSW_ELEMS = (size_t)K1 * K1 * P;
+    multibit_fill_roots<CFG>(root_lo, root_hi);
+    const uint32_t c_tau = multibit_slot_exponent<N>(tau);
+
+    const double2* gk = reinterpret_cast<const double2*>(args.fbsk) + (size_t)grp * (SEL + 1) * GGSW_ELEMS;
+    double2 gv[SEL + 1][K1][SLOTS];
+#pragma unroll
+    for (int s = 0; s <= SEL; s++)
+#pragma unroll
+        for (int r = 0; r < K1; r++)
+#pragma unroll
+            for (int h = 0; h < SLOTS; h++)
+                gv[s][r][h] = gk[(size_t)s * GGSW_ELEMS + ((size_t)((g + r) % K1) * K1 + g) * P + (rho0 + h) * T + tau];
+    __syncthreads();
+
+    const uint32_t first = blockIdx.z * CFG::COMBINE_CHUNK;
+    const uint32_t last = min(args.batch, first + CFG::COMBINE_CHUNK);
+    for (uint32_t sample = first; sample < last; sample++) {
+        const uint64_t* lwe = args.lwe_small + (size_t)sample * (n + 1) + (size_t)grp * G;
+        cplx comb[K1][SLOTS];
+#pragma unroll
+        for (int r = 0; r < K1; r++)
+#pragma unroll
+            for (int h = 0; h < SLOTS; h++) { comb[r][h].re = gv[0][r][h].x; comb[r][h].im = gv[0][r][h].y; }
+#pragma unroll
+        for (int s = 1; s <= SEL; s++) {
+            uint64_t sum = 0;
+#pragma unroll
+            for (int b = 0; b < G; b++)
+                if ((s >> (G - 1 - b)) & 1) sum += lwe[b];
+            const uint32_t d = modulus_switch(sum, LOGN);
+            cplx mono, turn;
+            multibit_monomial<CFG>(d, c_tau, root_lo, root_hi, mono, turn);
+            for (uint32_t q = 0; q < rho0; q++) mono = cmul(mono, turn);   // exact: entries of turn are 0 / +-1
+#pragma unroll
+            for (int h = 0; h < SLOTS; h++) {
+#pragma unroll
+                for (int r = 0; r < K1; r++) {
+                    const double2 v = gv[s][r][h];
+                    comb[r][h].re = fma(v.x, mono.re, fma(-v.y, mono.im, comb[r][h].re));
+                    comb[r][h].im = fma(v.x, mono.im, fma(v.y, mono.re, comb[r][h].im));
+                }
+                mono = cmul(mono, turn);
+            }
+        }
+        double2* out = ca.combined + ((size_t)sample * groups + grp) * GGSW_ELEMS;
+#pragma unroll
+        for (int r = 0; r < K1; r++)
+#pragma unroll
+            for (int h = 0; h < SLOTS; h++)
+                out[((size_t)((g + r) % K1) * K1 + g) * P + (rho0 + h) * T + tau] = make_double2(comb[r][h].re, comb[r][h].im);
+    }
+}
+
+// PRE: args.fbsk points at multibit_combine_kernel's output for this batch instead of the Fourier key
+template <int LOGN, int LOGR, int K1, int G, bool PRE = false>
 __global__ void __launch_bounds__((BrMultiBitCfg<LOGN, LOGR, K1, G>::THREADS))
 blind_rotate_multibit_kernel(BlindRotateArgs args) {
     using CFG = BrMultiBitCfg<LOGN, LOGR, K1, G>;
@@ -62,26 +186,18 @@ blind_rotate_multibit_kernel(BlindRotateArgs args) {
     double* xim = xre + BASE::PLANE;
     const uint32_t bL = args.base_log;
 
-    // monomial degrees of every group (:57-70: wrapping sum of the selected mask elements, then
-    // modulus switch), selector bit G-1-b <-> mask element b
-    for (uint32_t e = threadIdx.x; e < groups * SEL; e += CFG::THREADS) {
-        const uint32_t grp = e / SEL, sel = e % SEL + 1;
-        uint64_t sum = 0;
+    if constexpr (!PRE) {
+        // monomial degrees of every group (:57-70: wrapping sum of the selected mask elements, then
+        // modulus switch), selector bit G-1-b <-> mask element b
+        for (uint32_t e = threadIdx.x; e < groups * SEL; e += CFG::THREADS) {
+            const uint32_t grp = e / SEL, sel = e % SEL + 1;
+            uint64_t sum = 0;
 #pragma unroll
-        for (int b = 0; b < G; b++)
-            if ((sel >> (G - 1 - b)) & 1) sum += lwe[(size_t)grp * G + b];
-        lds_deg[e] = modulus_switch(sum, LOGN);
-    }
-    // e^{i pi m / N} = root_lo[m & mask] * root_hi[m >> ROOT_LO_BITS]
-    for (int e = threadIdx.x; e < (1 << CFG::ROOT_LO_BITS); e += CFG::THREADS) {
-        double sn, cs;
-        sincospi((double)e / (double)N, &sn, &cs);
-        root_lo[e] = make_double2(cs, sn);
-    }
-    for (int e = threadIdx.x; e < (1 << CFG::ROOT_HI_BITS); e += CFG::THREADS) {
-        double sn, cs;
-        sincospi((double)((size_t)e << CFG::ROOT_LO_BITS) / (double)N, &sn, &cs);
-        root_hi[e] = make_double2(cs, sn);
+            for (int b = 0; b < G; b++)
+                if ((sel >> (G - 1 - b)) & 1) sum += lwe[(size_t)grp * G + b];
+            lds_deg[e] = modulus_switch(sum, LOGN);
+        }
+        multibit_fill_roots<CFG>(root_lo, root_hi);
     }
 
     FftConsts<PL> fc;
@@ -93,11 +209,7 @@ blind_rotate_multibit_kernel(BlindRotateArgs args) {
         sincospi((double)PL::point(tau, m) / (double)N, &sn, &cs);
         twist[m].re = cs; twist[m].im = sn;
     }
-    // frequency of register slot 0 of this thread (FftSwap10: regs k4 | wave k3 | lane(5,4) k2 |
-    // lane(3,2) k0 | lane(1,0) k1, f = k0 + 4 k1 + 16 k2 + 64 k3 + 256 k4) and 1 - 4 f mod 2N
-    const int lane = tau & 63, wv = tau >> 6;
-    const uint32_t f_tau = ((lane >> 2) & 3) + 4 * (lane & 3) + 16 * (lane >> 4) + 64 * wv;
-    const uint32_t c_tau = (1u - 4u * f_tau) & (2u * N - 1u);
+    const uint32_t c_tau = multibit_slot_exponent<N>(tau);
 
     // acc <- LUT * X^{-ms(body)}
     uint64_t acc_lo[R], acc_hi[R];
@@ -123,14 +235,29 @@ blind_rotate_multibit_kernel(BlindRotateArgs args) {
     const double2* fbsk = reinterpret_cast<const double2*>(args.fbsk);
     constexpr size_t GGSW_ELEMS = (size_t)K1 * K1 * P;
 
+    double2 ahead[PRE ? K1 : 1][PRE ? R : 1];
+    auto request_ahead = [&](uint32_t grp) {
+        if constexpr (PRE) {
+            const double2* ck = fbsk + ((size_t)sample * groups + grp) * GGSW_ELEMS;
+#pragma unroll
+            for (int r = 0; r < K1; r++)
+#pragma unroll
+                for (int rho = 0; rho < R; rho++)
+                    ahead[r][rho] = ck[((size_t)((g + r) % K1) * K1 + g) * P + rho * T + tau];
+        }
+    };
+    request_ahead(0);
+
     for (uint32_t grp = 0; grp < groups; grp++) {
         // ---- request this group's 2^G GGSWs (column g, rows (g + r) % K1) now: they arrive from L2
         //      while the accumulator is decomposed and transformed ----
         //      (grouping factor 2: all four at once; 3: two in flight, the next one requested while the
         //      current one is folded in -- eight would need 256 VGPRs)
-        const double2* gk = fbsk + (size_t)grp * (SEL + 1) * GGSW_ELEMS;
-        constexpr bool PREFETCH_ALL = (SEL + 1) * K1 * R * 4 <= 96;
-        constexpr int NBUF = PREFETCH_ALL ? SEL + 1 : 2;
+        //      PRE: one GGSW, this LWE's combined one
+        const double2* gk = PRE ? fbsk + ((size_t)sample * groups + grp) * GGSW_ELEMS
+                                : fbsk + (size_t)grp * (SEL + 1) * GGSW_ELEMS;
+        constexpr bool PREFETCH_ALL = PRE || (SEL + 1) * K1 * R * 4 <= 96;
+        constexpr int NBUF = PRE ? 1 : (PREFETCH_ALL ? SEL + 1 : 2);
         double2 gv[NBUF][K1][R];
         auto request = [&](int s) {
 #pragma unroll
@@ -141,8 +268,16 @@ blind_rotate_multibit_kernel(BlindRotateArgs args) {
                     gv[s % NBUF][r][rho] = gk[(size_t)s * GGSW_ELEMS + ((size_t)row * K1 + g) * P + rho * T + tau];
             }
         };
+        if constexpr (PRE) {      // requested one step ahead: a whole step to arrive from HBM
 #pragma unroll
-        for (int s = 0; s < NBUF; s++) request(s);
+            for (int r = 0; r < K1; r++)
+#pragma unroll
+                for (int rho = 0; rho < R; rho++) gv[0][r][rho] = ahead[r][rho];
+            if (grp + 1 < groups) request_ahead(grp + 1);
+        } else {
+#pragma unroll
+            for (int s = 0; s < NBUF; s++) request(s);
+        }
 
         // ---- external product acc <- GGSW (x) acc (ggsw.rs:477-598 on a zeroed destination) ----
         cplx x[K1][R];
@@ -168,30 +303,22 @@ blind_rotate_multibit_kernel(BlindRotateArgs args) {
         for (int r = 0; r < K1; r++)
 #pragma unroll
             for (int rho = 0; rho < R; rho++) { comb[r][rho].re = gv[0][r][rho].x; comb[r][rho].im = gv[0][r][rho].y; }
+        if constexpr (!PRE) {
 #pragma unroll
-        for (int s = 1; s <= SEL; s++) {
-            if (!PREFETCH_ALL && s + 1 <= SEL) request(s + 1);      // into the buffer selector s-1 just left
-            const uint32_t d = lds_deg[grp * SEL + (s - 1)];
-            // monomial transform at slot rho: w^{d (1 - 4 f_tau)} * (-i)^{d rho}
-            const uint32_t mi = (d * c_tau) & (2u * N - 1u);
-            const double2 a = root_lo[mi & ((1u << CFG::ROOT_LO_BITS) - 1u)], b = root_hi[mi >> CFG::ROOT_LO_BITS];
-            cplx mono;
-            mono.re = a.x * b.x - a.y * b.y;
-            mono.im = a.x * b.y + a.y * b.x;
-            // (-i)^d as a complex number with entries in {0, +-1}
-            const int q = d & 3;
-            cplx turn;
-            turn.re = q == 0 ? 1.0 : q == 2 ? -1.0 : 0.0;
-            turn.im = q == 1 ? -1.0 : q == 3 ? 1.0 : 0.0;
+            for (int s = 1; s <= SEL; s++) {
+                if (!PREFETCH_ALL && s + 1 <= SEL) request(s + 1);      // into the buffer selector s-1 just left
+                cplx mono, turn;
+                multibit_monomial<CFG>(lds_deg[grp * SEL + (s - 1)], c_tau, root_lo, root_hi, mono, turn);
 #pragma unroll
-            for (int rho = 0; rho < R; rho++) {
+                for (int rho = 0; rho < R; rho++) {
 #pragma unroll
-                for (int r = 0; r < K1; r++) {
-                    const double2 v = gv[s % NBUF][r][rho];
-                    comb[r][rho].re = fma(v.x, mono.re, fma(-v.y, mono.im, comb[r][rho].re));
-                    comb[r][rho].im = fma(v.x, mono.im, fma(v.y, mono.re, comb[r][rho].im));
+                    for (int r = 0; r < K1; r++) {
+                        const double2 v = gv[s % NBUF][r][rho];
+                        comb[r][rho].re = fma(v.x, mono.re, fma(-v.y, mono.im, comb[r][rho].re));
+                        comb[r][rho].im = fma(v.x, mono.im, fma(v.y, mono.re, comb[r][rho].im));
+                    }
+                    mono = cmul(mono, turn);
                 }
-                mono = cmul(mono, turn);
             }
         }
 

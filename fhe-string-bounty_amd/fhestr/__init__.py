@@ -111,6 +111,7 @@ _lib = None
 EXPORTS = [
     "fhe_last_error", "fhe_kernel_revision", "fhe_engine_create", "fhe_engine_destroy", "fhe_engine_params",
     "fhe_engine_load_keys", "fhe_engine_generate_keys", "fhe_engine_stream", "fhe_engine_synchronize", "fhe_engine_set_variant",
+    "fhe_engine_set_multibit_combine_max",
     "fhe_lut_generate", "fhe_lut_upload", "fhe_lut_download", "fhe_lut_count",
     "fhe_keyswitch_batch", "fhe_pbs_batch", "fhe_ks_pbs_batch", "fhe_ks_pbs_batch_dev", "fhe_pbs_ks_batch",
     "fhe_lwe_lincomb_batch", "fhe_last_kernel_ms", "fhe_kernel_times",
@@ -175,6 +176,7 @@ def lib() -> C.CDLL:
     sig("fhe_chacha20_block", vp, C.c_uint64, C.c_uint64, vp)
     sig("fhe_engine_synchronize", vp)
     sig("fhe_engine_set_variant", vp, i32)
+    sig("fhe_engine_set_multibit_combine_max", vp, u32)
     sig("fhe_lut_generate", vp, vp, C.POINTER(u32), C.POINTER(C.c_uint64))
     sig("fhe_lut_upload", vp, vp, C.POINTER(u32))
     sig("fhe_lut_download", vp, u32, vp)
@@ -305,6 +307,10 @@ class Engine:
         _check(lib().fhe_engine_create(C.byref(params.c()), device, C.byref(self._h)))
         if log2_points:
             _check(lib().fhe_engine_set_variant(self._h, log2_points))
+
+    def set_multibit_combine_max(self, max_batch: int):
+        """Multi-bit PBS: batches up to max_batch prepare their GGSWs on the whole GPU first (0 = always fused)."""
+        _check(lib().fhe_engine_set_multibit_combine_max(self._h, max_batch))
 
     def close(self):
         if self._h:

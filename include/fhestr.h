@@ -80,6 +80,12 @@ int fhe_engine_reset_stream(fhe_engine *eng);
 int fhe_engine_synchronize(fhe_engine *eng);
 /* Choose the blind-rotation variant: points per thread = 2^log2_points (0 = automatic). */
 int fhe_engine_set_variant(fhe_engine *eng, int log2_points);
+/* Multi-bit PBS only: batches of up to max_batch LWEs build every (LWE, group) GGSW on the whole GPU first
+ * (prepare_multi_bit_ggsw, lwe_multi_bit_programmable_bootstrapping.rs:18-83, which the reference runs on
+ * separate threads) and then rotate against them; larger batches fuse both into one kernel.  Default 64
+ * (env FHESTR_MULTIBIT_COMBINE_MAX); 0 = always fused.  Both paths give bit-identical ciphertexts.  Costs
+ * max_batch * (n / grouping_factor) * (k+1)^2 * N * 8 bytes of device workspace when used. */
+int fhe_engine_set_multibit_combine_max(fhe_engine *eng, uint32_t max_batch);
 
 /* ---- lookup tables ------------------------------------------------------------------------- */
 /* generate_lookup_table (shortint/server_key/mod.rs:383-399, engine/mod.rs:72-128):

@@ -1,19 +1,26 @@
 """PBS/s of the multi-bit PBS (PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS) next to the classic one
-(PARAM_MESSAGE_2_CARRY_2_KS_PBS): device-generated keys, decrypt-checked."""
-import sys, time
+(PARAM_MESSAGE_2_CARRY_2_KS_PBS): device-generated keys, decrypt-checked.
+
+    python3 scripts/multibit_bench.py [B ...]      (default 1 64 256 1024)
+
+FHESTR_MULTIBIT_COMBINE_MAX=0 forces the fused kernel for every batch size (default: batches <= 64 prepare the
+groups' GGSWs on the whole GPU first); MULTIBIT_ONLY=1 skips the classic parameter set."""
+import os, sys, time
 import numpy as np
 sys.path.insert(0, "fhe-string-bounty_amd")
 import fhestr
 
-for P in (fhestr.PARAM_MESSAGE_2_CARRY_2_KS_PBS, fhestr.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS,
-          fhestr.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS):
+BATCHES = [int(a) for a in sys.argv[1:]] or [1, 64, 256, 1024]
+SETS = (fhestr.PARAM_MESSAGE_2_CARRY_2_KS_PBS, fhestr.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS,
+        fhestr.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS)
+for P in SETS[1 if os.environ.get("MULTIBIT_ONLY") else 0:]:
     ck = fhestr.ClientKey(P, 0x5EED0002)
     g, s = ck.secret_keys()
     eng = fhestr.Engine(P, 0)
     eng.generate_keys(g, s, 0x5EED0002)
     lut, _ = eng.generate_lookup_table(lambda x: (x * x + 1) % 16)
     rng = np.random.default_rng(3)
-    for B in (1, 64, 256, 1024):
+    for B in BATCHES:
         msgs = rng.integers(0, 16, size=B)
         cts = ck.encrypt(msgs)
         idx = np.full(B, lut, dtype=np.uint32)

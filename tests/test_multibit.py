@@ -98,6 +98,12 @@ def test_gpu_multi_bit_pbs_matches_oracle(p):
         assert np.array_equal(eng.keyswitch(cts), np.stack([sk.keyswitch(c) for c in cts]))     # bit-exact
         got = eng.apply_lookup_table(cts, np.full(len(cts), lut_id, dtype=np.uint32))
         assert np.array_equal(ck.decrypt_many(got), [f(int(m)) for m in msgs])
+        # 32 LWEs took the two-kernel path (GGSWs of every group prepared on the whole GPU, then n/G plain
+        # external products); the fused kernel does the same operations in the same order
+        eng.set_multibit_combine_max(0)
+        fused = eng.apply_lookup_table(cts, np.full(len(cts), lut_id, dtype=np.uint32))
+        assert np.array_equal(got, fused)
+        eng.set_multibit_combine_max(64)
         # phase of the GPU result against the oracle's f64 path on the first few LWEs
         want = sk.apply_lookup_table_batch(cts[:4], lut)
         logN = p.N.bit_length() - 1
