@@ -209,6 +209,60 @@ def test_sharded_runner_gpu_backend_single_rank(toy_k1):
             dist.destroy_process_group()
 
 
+class _LoopbackRanks:
+    """All ranks of a sharded plan on ONE GPU: every simulated rank owns a pool in HBM and runs its share of each
+    level through the product kernels (fhe_plan_run_level_rank_dev); the all-gather is replaced by the copies it
+    stands for (rank q's exported region -> slot q of every rank's receive region)."""
+
+    def __init__(self, plan, world):
+        import torch
+        from fhestr.distributed import GpuBackend
+        self.torch, self.plan, self.world = torch, plan, world
+        self.backend = GpuBackend(plan, torch.device("cuda", 0))
+        self.info = plan.info()
+        self.levels = [plan.level_info(l) for l in range(self.info["n_levels"])]
+
+    def run(self, inputs):
+        b = self.backend
+        pools = [b.alloc_pool(self.info["pool_slots"]) for _ in range(self.world)]
+        for pool in pools:
+            b.load_inputs(pool, inputs, self.info["n_inputs"])
+        for l, lv in enumerate(self.levels):
+            for r, pool in enumerate(pools):
+                b.run_level(pool, l, r)
+            e = lv["e_max"]
+            if e:
+                for pool in pools:
+                    for q, src in enumerate(pools):
+                        pool[lv["recv_base"] + q * e: lv["recv_base"] + (q + 1) * e].copy_(src[lv["local_base"]: lv["local_base"] + e])
+        return [b.gather_outputs(pool, self.info["n_outputs"]) for pool in pools]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_plan_all_ranks_on_one_gpu(p22, world):
+    """SURVEY 8(e) on the product kernels: eq (256 chars) and contains (16 in 256) built for `world` ranks, every
+    rank's level shares run on this GPU with rank-local pools; each rank ends with the right answer and only the
+    exported ciphertexts crossed."""
+    import fhestr
+    eng = _ops(p22).engine
+    rng = np.random.default_rng(0x5EED0004)
+    hay = bytes(rng.integers(0x61, 0x7B, size=256, dtype=np.uint8))
+    off = int(rng.integers(0, 240))
+    try:
+        for op, b_cap, second, want in (("eq", 256, hay, 1), ("eq", 256, hay[:100] + b"#" + hay[101:], 0),
+                                        ("contains", 16, hay[off: off + 16], 1), ("contains", 16, b"0123456789ABCDEF", 0)):
+            plan = fhestr.Plan.string_op(eng, op, 256, b_cap, world=world)
+            inputs = np.concatenate([_enc(p22, hay, 256), _enc(p22, second, b_cap)])
+            ranks = _LoopbackRanks(plan, world)
+            outs = ranks.run(inputs)
+            assert [int(_dec(p22, o)[0]) for o in outs] == [want] * world, (op, world)
+            crossing = sum(lv["e_max"] * world for lv in ranks.levels)
+            assert crossing < plan.info()["n_pbs"] // 8      # only reduced ciphertexts cross, not the level outputs
+            plan.close()
+    finally:
+        eng.set_stream(None)
+
+
 def test_string_ops_with_4_bit_blocks_large_n():
     """BASELINE.json config 5 geometry: msg_mod = carry_mod = 16 (one char = 2 blocks) on the
     N = 32768 polynomial size of PARAM_MESSAGE_4_CARRY_4 (toy LWE dimension so keys are quick)."""
