@@ -77,7 +77,7 @@ def cpu_baseline(P, bsk, ksk, cts, lut_tables, lut_sel):
             "seconds": dt}, out
 
 
-def bench_strings(fhestr, eng, ck, P, rank, world, local_rank, reps=3):
+def bench_strings(fhestr, eng, ck, P, rank, world, local_rank, reps=3, staged=False):
     """ms/op of FheString::eq (256 vs 256 chars, both encrypted) and ::contains (16-char encrypted
     pattern in a 256-char haystack); every level's KS+PBS batch is split over the ranks."""
     import torch
@@ -117,7 +117,7 @@ def bench_strings(fhestr, eng, ck, P, rank, world, local_rank, reps=3):
     dev = torch.device("cuda", local_rank)
     for name, (op, a_cap, b_cap, clear, inputs, check, n_rep) in cases.items():
         plan = fhestr.Plan.string_op(eng, op, a_cap, b_cap, clear=clear, world=world)
-        runner = ShardedPlanRunner(plan, rank, world, GpuBackend(plan, dev))
+        runner = ShardedPlanRunner(plan, rank, world, GpuBackend(plan, dev, staged=staged))
         res = runner.run(inputs)   # warm-up + correctness
         ok = bool(check(ck.decrypt(res)))
         d_inputs = torch.from_numpy(inputs.view(np.int64)).to(dev)
@@ -354,9 +354,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # FHESTR_BENCH_REHEARSAL=1: every rank on GPU 0 with a gloo group and host-staged gathers -- walks the N > 1
+    # code path on a one-GPU box (RCCL refuses two ranks on one device); its numbers mean nothing and say so
+    rehearsal = world > 1 and os.environ.get("FHESTR_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    coll_dev = "cpu" if rehearsal else "cuda"
 
     P = fhestr.PARAM_MESSAGE_2_CARRY_2_KS_PBS
     B = args.batch
@@ -406,7 +415,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ks_ms, br_ms, calls = eng.kernel_times(reset=True)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
@@ -416,7 +425,7 @@ def main():
     dec = ck.decrypt(got)
     verified = bool(np.array_equal(dec, tables[sel, msgs]))
     if world > 1:
-        v = torch.tensor([1 if verified else 0], device="cuda")
+        v = torch.tensor([1 if verified else 0], device=coll_dev)
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
         verified = bool(v.item())
 
@@ -454,6 +463,8 @@ def main():
             "kernel_ms": {"keyswitch": ks_ms / max(calls, 1), "blind_rotate": br_avg_ms, "launches": calls,
                           "kernel_revision": fhestr.kernel_revision()},
             "verified_decrypt": verified,
+            **({"rehearsal": "all ranks share GPU 0 (gloo, host-staged gathers): code-path check only, not a measurement"}
+               if rehearsal else {}),
             "string_ops": None,
             "batch_sweep_pbs_per_s": sweep,
         }
@@ -475,7 +486,7 @@ def main():
         dog.daemon = True
         dog.start()
         try:
-            string_ops = bench_strings(fhestr, eng, ck, P, rank, world, local_rank)
+            string_ops = bench_strings(fhestr, eng, ck, P, rank, world, local_rank, staged=rehearsal)
         except Exception as e:   # never let the secondary section take the headline number down
             string_ops = {"error": f"{type(e).__name__}: {e}"}
         dog.cancel()

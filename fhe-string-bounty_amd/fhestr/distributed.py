@@ -39,14 +39,16 @@ class ShardedPlanRunner:
 
 
 class GpuBackend:
-    """Product backend: pool in HBM (torch tensor), HIP kernels via the C ABI, RCCL all-gather."""
+    """Product backend: pool in HBM (torch tensor), HIP kernels via the C ABI, RCCL all-gather.
+    staged=True gathers through host memory instead (gloo group: rehearsing several ranks on one GPU)."""
 
-    def __init__(self, plan, device, group=None):
+    def __init__(self, plan, device, group=None, staged=False):
         import torch
         self.torch = torch
         self.plan = plan
         self.device = device
         self.group = group
+        self.staged = staged
         self.big = plan.params.big_size
         # kernels and collectives on the same stream: no host synchronisation between them
         plan.engine.set_stream(torch.cuda.current_stream(device).cuda_stream)
@@ -66,6 +68,13 @@ class GpuBackend:
 
     def all_gather(self, pool, local_base, e_max, recv_base, world):
         import torch.distributed as dist
+        if self.staged:
+            self.torch.cuda.current_stream(self.device).synchronize()
+            mine = pool[local_base: local_base + e_max].cpu()
+            everyone = self.torch.empty((e_max * world, self.big), dtype=mine.dtype)
+            dist.all_gather_into_tensor(everyone, mine, group=self.group)
+            pool[recv_base: recv_base + e_max * world].copy_(everyone)
+            return
         dist.all_gather_into_tensor(pool[recv_base: recv_base + e_max * world],
                                     pool[local_base: local_base + e_max], group=self.group)
 
