@@ -60,6 +60,8 @@ struct Engine {
     // staging / scratch (grown on demand)
     uint64_t *d_in = nullptr, *d_small = nullptr, *d_small2 = nullptr, *d_out = nullptr, *d_pool = nullptr;
     uint32_t* d_idx = nullptr;
+    uint32_t* d_slot_exp = nullptr;   // multi-bit two-kernel path: exponent of w = e^{i pi / N} each Fourier slot evaluates at
+    size_t multibit_workspace_cap = (size_t)8 << 30;   // prepared GGSWs kept at once (larger batches run in sub-batches)
     void* d_meta = nullptr;
     void* d_ws = nullptr;      // per-LWE HBM workspace of the large-N blind rotation
     size_t cap_ws = 0;
@@ -73,6 +75,8 @@ struct Engine {
     int generate_keys(const uint64_t* glwe_sk, const uint64_t* small_sk, const uint8_t seed[32],
                       uint64_t* bsk_std_out, uint64_t* ksk_out);
     int install_keys(uint64_t* d_ksk_std, uint64_t* d_bsk_std);
+    int convert_polys(const uint64_t* d_std, double* d_out, uint32_t n_polys);
+    int probe_slot_exponents();
     uint64_t fill_accumulator(const uint64_t* table, std::vector<uint64_t>& acc) const { return fhe::fill_accumulator(p, table, acc); }
     int lut_upload_dedup(const std::vector<uint64_t>& acc, uint32_t* id);   // same contents -> same id
     int set_stream(hipStream_t s, bool use_own);   // launch on a caller-owned stream (e.g. the framework's current stream)

@@ -9,6 +9,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -58,6 +59,9 @@ struct BrVariant {
     int combine_grid_y = 1;
     int combine_chunk = 1;
     size_t combined_bytes = 0;    // one combined GGSW
+    // multi-bit on every other shape: two-kernel path only (generic combine + the classic kernel's EXTPROD mode)
+    const void* extprod_fn = nullptr;
+    const void* combine_generic_fn = nullptr;
 };
 
 template <int LOGN, int LOGR, int K1, int L>
@@ -119,6 +123,32 @@ BrVariant make_multibit_variant() {
     return v;
 }
 
+// Multi-bit PBS for a shape served by the classic split kernel / the large-N kernel: same Fourier key layout and
+// conversion, rotation = EXTPROD mode against GGSWs prepared by multibit_combine_generic_kernel.
+template <int LOGN, int LOGR, int K1, int L>
+BrVariant make_multibit_generic_variant(int G) {
+    BrVariant v = make_variant<LOGN, LOGR, K1, L>();
+    v.grouping = G;
+    v.extprod_fn = reinterpret_cast<const void*>(&blind_rotate_kernel<LOGN, LOGR, K1, L, true>);
+    v.rotate_fn = v.extprod_fn;
+    v.combine_generic_fn = G == 2 ? reinterpret_cast<const void*>(&multibit_combine_generic_kernel<2>)
+                                  : reinterpret_cast<const void*>(&multibit_combine_generic_kernel<3>);
+    v.combined_bytes = (size_t)L * K1 * K1 * (size_t)(1 << (LOGN - 1)) * 16;
+    return v;
+}
+
+template <int LOGN, int K1, int L>
+BrVariant make_multibit_large_variant(int G) {
+    BrVariant v = make_large_variant<LOGN, K1, L>();
+    v.grouping = G;
+    v.extprod_fn = reinterpret_cast<const void*>(&blind_rotate_large_kernel<LOGN, K1, L, true>);
+    v.rotate_fn = v.extprod_fn;
+    v.combine_generic_fn = G == 2 ? reinterpret_cast<const void*>(&multibit_combine_generic_kernel<2>)
+                                  : reinterpret_cast<const void*>(&multibit_combine_generic_kernel<3>);
+    v.combined_bytes = (size_t)L * K1 * K1 * (size_t)(1 << (LOGN - 1)) * 16;
+    return v;
+}
+
 static const std::vector<BrVariant>& variants() {
     static const std::vector<BrVariant> v = {
         // PARAM_MESSAGE_2_CARRY_2_KS_PBS: N=2048, k=1, l=1  (first entry of a shape = default)
@@ -128,6 +158,13 @@ static const std::vector<BrVariant>& variants() {
         make_multibit_variant<11, 2, 2, 2>(),
         // PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS: grouping factor 3 (8 GGSWs per group)
         make_multibit_variant<11, 2, 2, 3>(),
+        // PARAM_MULTI_BIT_MESSAGE_1_CARRY_1_GROUP_{2,3}_KS_PBS (N = 512, k = 3) and
+        // PARAM_MULTI_BIT_MESSAGE_3_CARRY_3_GROUP_{2,3}_KS_PBS (N = 8192, two levels): two-kernel path
+        make_multibit_generic_variant<9, 2, 4, 1>(2), make_multibit_generic_variant<9, 2, 4, 1>(3),
+        make_multibit_large_variant<13, 2, 2>(2), make_multibit_large_variant<13, 2, 2>(3),
+        // toy shapes of the multi-bit tests (N = 256, k = 1, two levels; N = 128, k = 2)
+        make_multibit_generic_variant<8, 2, 2, 2>(2), make_multibit_generic_variant<8, 2, 2, 2>(3),
+        make_multibit_generic_variant<7, 2, 3, 1>(2), make_multibit_generic_variant<7, 2, 3, 1>(3),
         // N=1024, k=2, l=1 family (PARAM_MESSAGE_2_CARRY_1_KS_PBS ...)
         make_variant<10, 3, 3, 1>(), make_variant<10, 2, 3, 1>(), make_wide_variant<10, 2, 3, 1>(),
         // PARAM_MESSAGE_1_CARRY_1_KS_PBS: N=512, k=3, l=1
@@ -206,7 +243,7 @@ Engine::~Engine() {
     if (stream) (void)hipStreamSynchronize(stream);
     auto rel = [](void* ptr) { if (ptr) (void)hipFree(ptr); };
     rel(d_ksk); rel(d_ksk_packed); rel(d_fbsk); rel(d_luts); rel(d_in); rel(d_small); rel(d_small2); rel(d_out); rel(d_idx);
-    rel(d_pool); rel(d_meta); rel(d_ws);
+    rel(d_pool); rel(d_meta); rel(d_ws); rel(d_slot_exp);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ring) if (e) (void)hipEventDestroy(e);
     if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -327,6 +364,62 @@ int Engine::generate_keys(const uint64_t* glwe_sk, const uint64_t* small_sk, con
 
 // Takes ownership of the two standard-domain device buffers: repacks the KSK into byte planes and
 // converts the BSK to the active variant's Fourier layout, then releases them.
+// Standard-domain polynomials -> the variant's Fourier layout (bsk_convert_kernel / bsk_convert_large_kernel).
+int Engine::convert_polys(const uint64_t* d_std, double* d_out, uint32_t n_polys) {
+    const uint32_t k1 = p.k + 1;
+    HIP_TRY(hipFuncSetAttribute(variant->convert_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)variant->convert_lds));
+    if (variant->large) {
+        const uint32_t blocks = n_polys < (uint32_t)cu_count ? n_polys : (uint32_t)cu_count;
+        void* d_cws = nullptr;
+        HIP_TRY(hipMalloc(&d_cws, (size_t)blocks * variant->convert_ws));
+        void* args[] = {(void*)&d_std, (void*)&d_out, (void*)&n_polys, (void*)&d_cws};
+        hipError_t e = hipLaunchKernel(variant->convert_fn, dim3(blocks), dim3(variant->convert_threads), args,
+                                       variant->convert_lds, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(d_cws);
+        if (e != hipSuccess) return fail(std::string("bsk conversion: ") + hipGetErrorString(e));
+        return 0;
+    }
+    void* args[] = {(void*)&d_std, (void*)&d_out, (void*)&n_polys};
+    HIP_TRY(hipLaunchKernel(variant->convert_fn, dim3((n_polys + k1 - 1) / k1), dim3(variant->convert_threads),
+                            args, variant->convert_lds, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
+// Which power of w = e^{i pi / N} each slot of the Fourier layout evaluates at: transform the monomial X with the
+// variant's own conversion kernel and read the angles off (pbs_multibit_kernels.hip.h, "any other shape").
+int Engine::probe_slot_exponents() {
+    const uint32_t k1 = p.k + 1, P = p.N / 2;
+    std::vector<uint64_t> mono((size_t)k1 * p.N, 0);
+    for (uint32_t r = 0; r < k1; r++) mono[(size_t)r * p.N + 1] = 1;
+    uint64_t* d_mono = nullptr;
+    double* d_spec = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_mono, mono.size() * 8));
+    HIP_TRY(hipMalloc((void**)&d_spec, mono.size() * 8));
+    HIP_TRY(hipMemcpy(d_mono, mono.data(), mono.size() * 8, hipMemcpyHostToDevice));
+    int rc = convert_polys(d_mono, d_spec, k1);
+    std::vector<double> spec((size_t)P * 2);
+    if (!rc && hipMemcpy(spec.data(), d_spec, spec.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("slot probe: copy");
+    (void)hipFree(d_mono);
+    (void)hipFree(d_spec);
+    if (rc) return rc;
+    std::vector<uint32_t> expo(P);
+    const double pi = 3.14159265358979323846;
+    for (uint32_t s = 0; s < P; s++) {
+        const double turns = std::atan2(spec[2 * s + 1], spec[2 * s]) / pi * (double)p.N;   // in units of pi / N
+        const long e = std::lround(turns);
+        expo[s] = (uint32_t)(((e % (long)(2 * p.N)) + 2 * p.N) % (2 * p.N));
+        if (std::fabs(turns - (double)e) > 0.01 || (expo[s] & 1) == 0)     // roots of X^N + 1 are the odd powers of w
+            return fail("slot probe: the conversion kernel did not return a root of X^N + 1");
+    }
+    if (d_slot_exp) { HIP_TRY(hipFree(d_slot_exp)); d_slot_exp = nullptr; }
+    HIP_TRY(hipMalloc((void**)&d_slot_exp, (size_t)P * 4));
+    HIP_TRY(hipMemcpy(d_slot_exp, expo.data(), (size_t)P * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
 int Engine::install_keys(uint64_t* d_ksk_std, uint64_t* d_std) {
     struct Guard {
         uint64_t*& a; uint64_t*& b;
@@ -349,26 +442,8 @@ int Engine::install_keys(uint64_t* d_ksk_std, uint64_t* d_std) {
         d_ksk_std = nullptr;          // kept: the mad64 kernel reads the 64-bit layout
     }
     HIP_TRY(hipMalloc((void**)&d_fbsk, bsk_len * 8));   // N u64 -> N/2 c64: same byte count
-    const uint32_t n_polys = (uint32_t)(bsk_len / p.N);
-    const uint32_t k1 = p.k + 1;
-    HIP_TRY(hipFuncSetAttribute(variant->convert_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)variant->convert_lds));
-    if (variant->large) {
-        const uint32_t blocks = n_polys < (uint32_t)cu_count ? n_polys : (uint32_t)cu_count;
-        void* d_cws = nullptr;
-        HIP_TRY(hipMalloc(&d_cws, (size_t)blocks * variant->convert_ws));
-        void* args[] = {(void*)&d_std, (void*)&d_fbsk, (void*)&n_polys, (void*)&d_cws};
-        hipError_t e = hipLaunchKernel(variant->convert_fn, dim3(blocks), dim3(variant->convert_threads), args,
-                                       variant->convert_lds, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        (void)hipFree(d_cws);
-        if (e != hipSuccess) return fail(std::string("bsk conversion: ") + hipGetErrorString(e));
-    } else {
-        void* args[] = {(void*)&d_std, (void*)&d_fbsk, (void*)&n_polys};
-        HIP_TRY(hipLaunchKernel(variant->convert_fn, dim3((n_polys + k1 - 1) / k1), dim3(variant->convert_threads),
-                                args, variant->convert_lds, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-    }
+    if (convert_polys(d_std, d_fbsk, (uint32_t)(bsk_len / p.N))) return 1;
+    if (variant->combine_generic_fn && probe_slot_exponents()) return 1;
     HIP_TRY(hipFuncSetAttribute(variant->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(variant->lds_bytes + (size_t)p.n * variant->lds_per_n)));
     HIP_TRY(hipFuncSetAttribute(variant_large->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -483,6 +558,41 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
         void* bargs[] = {(void*)&b};
         HIP_TRY(hipLaunchKernel(v->rotate_combined_fn, dim3(count), dim3(v->threads), bargs,
                                 v->lds_bytes + (size_t)p.n * v->lds_per_n, stream));
+        return 0;
+    }
+    if (v->extprod_fn) {
+        // multi-bit PBS on a shape without a fused kernel: prepare the (LWE, group) GGSWs, then n/G external
+        // products per LWE; sub-batches keep the prepared GGSWs within a fixed workspace
+        const size_t groups = p.n / p.grouping_factor, per_lwe = groups * v->combined_bytes;
+        const size_t rot_ws = v->large ? v->ws_bytes : 0;
+        const uint32_t sub_max = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, multibit_workspace_cap / (per_lwe + rot_ws)));
+        if (ensure(&d_ws, &cap_ws, (size_t)sub_max * (per_lwe + rot_ws))) return 1;
+        unsigned char* rot_base = reinterpret_cast<unsigned char*>(d_ws) + (size_t)sub_max * per_lwe;
+        uint32_t logN = 0;
+        while ((1u << logN) < p.N) logN++;
+        const uint32_t ggsw_elems = (uint32_t)(v->combined_bytes / 16);
+        const size_t combine_lds = ((size_t)(1u << ((logN + 1) / 2)) + (size_t)(1u << (logN + 1 - (logN + 1) / 2))) * 16;
+        const size_t big = (size_t)p.k * p.N + 1;
+        for (uint32_t first = 0; first < count; first += sub_max) {
+            const uint32_t sub = std::min(sub_max, count - first);
+            MultiBitCombineGenericArgs ca{d_sm + (size_t)first * (p.n + 1), reinterpret_cast<const double2*>(d_fbsk), d_slot_exp,
+                                          reinterpret_cast<double2*>(d_ws), p.n, logN, p.N / 2, ggsw_elems, sub};
+            void* cargs[] = {(void*)&ca};
+            HIP_TRY(hipLaunchKernel(v->combine_generic_fn, dim3((unsigned)groups, (ggsw_elems + 511) / 512, (sub + 7) / 8), dim3(256),
+                                    cargs, combine_lds, stream));
+            BlindRotateArgs b{d_sm + (size_t)first * (p.n + 1), d_lut_idx ? d_lut_idx + first : nullptr, d_luts,
+                              reinterpret_cast<const double*>(d_ws), d_big + (size_t)first * big, p.n, p.pbs_base_log, sub,
+                              p.grouping_factor};
+            if (v->large) {
+                BlindRotateLargeArgs la{b, rot_base};
+                void* largs[] = {(void*)&la};
+                HIP_TRY(hipLaunchKernel(v->extprod_fn, dim3(sub), dim3(v->threads), largs, v->lds_bytes, stream));
+            } else {
+                void* bargs[] = {(void*)&b};
+                HIP_TRY(hipLaunchKernel(v->extprod_fn, dim3(sub), dim3(v->threads), bargs,
+                                        v->lds_bytes + (size_t)p.n * v->lds_per_n, stream));
+            }
+        }
         return 0;
     }
     if (v->large) {

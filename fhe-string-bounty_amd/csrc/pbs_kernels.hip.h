@@ -56,6 +56,7 @@ struct BlindRotateArgs {
     uint32_t n;                  // small LWE dimension
     uint32_t base_log;           // PBS decomposition base log
     uint32_t batch;
+    uint32_t grouping;           // EXTPROD kernels only: mask elements per step (multi-bit grouping factor)
 };
 
 // ((x >> (63 - bL)) + 1) >> 1 masked to bL bits == closest_representable(x) >> (64 - bL)
@@ -263,10 +264,14 @@ bsk_convert_kernel(const uint64_t* __restrict__ bsk_std, double* __restrict__ fb
 //   lds_d   [n] u32          modulus-switched mask elements (0xFFFFFFFF marks a_i == 0)
 // Barriers per CMUX step: forward exchange 0->1, spectrum publish, inverse exchange 1->0, accumulator
 // publish; every other exchange is wave-local.
-template <int LOGN, int LOGR, int K1, int L>
+// EXTPROD (multi-bit PBS through the two-kernel path, pbs_multibit_kernels.hip.h): n / grouping steps, each
+// a plain external product acc <- GGSW (x) acc on a zeroed destination (no rotate-and-subtract, no
+// accumulate) against this LWE's own prepared GGSWs, args.fbsk = [batch][n / grouping] GGSWs in key layout.
+template <int LOGN, int LOGR, int K1, int L, bool EXTPROD = false>
 __global__ void __launch_bounds__((BrCfg<LOGN, LOGR, K1, L>::THREADS))
 blind_rotate_kernel(BlindRotateArgs args) {
     using CFG = BrCfg<LOGN, LOGR, K1, L>;
+    static_assert(!EXTPROD || !CFG::PL::SWAP, "N = 2048 has its own multi-bit kernels");
     using PL = typename CFG::PL;
     constexpr int N = CFG::N, P = CFG::P, R = CFG::R, T = CFG::T;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -295,9 +300,10 @@ blind_rotate_kernel(BlindRotateArgs args) {
     const uint32_t dbias = decomp_bias_constant(bL <= 31 ? bL : 31);
 
     // modulus switch of the whole mask once (fft_impl/common.rs:26-43); a_i == 0 is skipped (:281)
-    for (uint32_t i = threadIdx.x; i < n; i += CFG::THREADS) {
+    const uint32_t steps = EXTPROD ? n / args.grouping : n;
+    for (uint32_t i = threadIdx.x; i < steps; i += CFG::THREADS) {
         const uint64_t a = lwe[i];
-        lds_d[i] = a == 0 ? 0xFFFFFFFFu : modulus_switch(a, LOGN);
+        lds_d[i] = EXTPROD ? 0u : (a == 0 ? 0xFFFFFFFFu : modulus_switch(a, LOGN));
     }
 
     // per-thread constants: inter-pass twiddles and twisties (1/P is folded into the Fourier key)
@@ -345,14 +351,16 @@ blind_rotate_kernel(BlindRotateArgs args) {
 
     uint32_t d_next = lds_d[0];
     const uint32_t key_off = (uint32_t)tau * 16u;     // this thread's byte offset inside a Fourier polynomial row
-    const auto key_rsrc = key_resource(args.fbsk, (size_t)n * GGSW_ELEMS * 16);
+    // (EXTPROD: the resource covers this LWE's GGSWs only -- offsets stay below 2^32)
+    if constexpr (EXTPROD) fbsk += (size_t)sample * steps * GGSW_ELEMS;
+    const auto key_rsrc = key_resource(reinterpret_cast<const double*>(fbsk), (size_t)steps * GGSW_ELEMS * 16);
     FHE_STAMP_DECL;
     FHE_STAMP(-1);
-    for (uint32_t i = 0; i < n; i++) {
+    for (uint32_t i = 0; i < steps; i++) {
         // the modulus-switched mask element is the same for the whole workgroup: as a scalar, the rotation's
         // uniform parts (quotient, remainder, sign) cost no vector instructions
         const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)d_next);
-        d_next = lds_d[i + 1 < n ? i + 1 : i];                  // prefetch (LDS broadcast read)
+        d_next = lds_d[i + 1 < steps ? i + 1 : i];              // prefetch (LDS broadcast read)
         if (d == 0xFFFFFFFFu) continue;                          // block-uniform
         const Rotation<PL, LOGN> rot(d, tau);
 
@@ -383,6 +391,12 @@ blind_rotate_kernel(BlindRotateArgs args) {
         for (int m = 0; m < R; m++) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
+                if constexpr (EXTPROD) {                         // the accumulator itself is decomposed
+                    const uint64_t own = h == 0 ? acc_lo[m] : acc_hi[m];
+                    const uint32_t st = L == 1 ? decomp_single_biased(own, bL, dbias) : decomp_init_state(own, bL);
+                    if (h == 0) st_lo[m] = st; else st_hi[m] = st;
+                    continue;
+                }
                 uint32_t sm32;                                   // (acc*X^d)[j] = +-acc[j - rem], select-free
                 uint64_t gathered;
                 if constexpr (PL::SWAP) {
@@ -521,6 +535,11 @@ blind_rotate_kernel(BlindRotateArgs args) {
 #pragma unroll
         for (int m = 0; m < R; m++) {
             cplx t = cmul_conj(outf[m], twist[m]);
+            if constexpr (EXTPROD) {
+                acc_lo[m] = from_torus(t.re);
+                acc_hi[m] = from_torus(t.im);
+                continue;
+            }
             acc_lo[m] += from_torus(t.re);
             acc_hi[m] += from_torus(t.im);
             my_acc[acc_slot_of<PL>(PL::point(tau, m))] = acc_lo[m];

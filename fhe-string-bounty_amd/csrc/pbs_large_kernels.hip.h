@@ -208,7 +208,8 @@ struct BlindRotateLargeArgs {
 };
 
 // ------------------------------------------------------------------------------------------------
-template <int LOGN, int K1, int L>
+// EXTPROD: see blind_rotate_kernel (multi-bit PBS through the two-kernel path)
+template <int LOGN, int K1, int L, bool EXTPROD = false>
 __global__ void __launch_bounds__((BrLargeCfg<LOGN, K1, L>::THREADS))
 blind_rotate_large_kernel(BlindRotateLargeArgs la) {
     using CFG = BrLargeCfg<LOGN, K1, L>;
@@ -264,12 +265,14 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
     const double2* fbsk = reinterpret_cast<const double2*>(args.fbsk);
     constexpr size_t GGSW_ELEMS = (size_t)L * K1 * K1 * P;
 
+    const uint32_t steps = EXTPROD ? n / args.grouping : n;
+    if constexpr (EXTPROD) fbsk += (size_t)sample * steps * GGSW_ELEMS;
     FHE_STAMP_DECL;
     FHE_STAMP(-1);
-    for (uint32_t i = 0; i < n; i++) {
+    for (uint32_t i = 0; i < steps; i++) {
         if (tid == 0) {
             const uint64_t a = lwe[i];
-            s_d = a == 0 ? 0xFFFFFFFFu : modulus_switch(a, LOGN);
+            s_d = EXTPROD ? 0u : (a == 0 ? 0xFFFFFFFFu : modulus_switch(a, LOGN));
         }
         __syncthreads();
         FHE_STAMP(0);    // step head (mask element broadcast)
@@ -293,7 +296,7 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         const uint32_t j = (tauA + CFG::TA * m) * P2 + b + h * P;
-                        rot[2 * m + h] = ap[CFG::aix((j - rem) & (N - 1))];
+                        if constexpr (!EXTPROD) rot[2 * m + h] = ap[CFG::aix((j - rem) & (N - 1))];
                         own[2 * m + h] = ap[CFG::aix(j)];
                     }
                 }
@@ -309,11 +312,12 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
                     for (int h = 0; h < 2; h++) {
                         const uint32_t j = (tauA + CFG::TA * m) * P2 + b + h * P;
                         const bool neg = (j < rem) != odd;
-                        uint64_t v = rot[2 * m + h];
+                        uint64_t v = EXTPROD ? 0 : rot[2 * m + h];
                         v = neg ? (0 - v) : v;
+                        const uint64_t ct1 = EXTPROD ? own[2 * m + h] : v - own[2 * m + h];
                         state_t st;
-                        if constexpr (L >= 3) st = decomp_init_state64(v - own[2 * m + h], bL);
-                        else st = decomp_init_state(v - own[2 * m + h], bL);
+                        if constexpr (L >= 3) st = decomp_init_state64(ct1, bL);
+                        else st = decomp_init_state(ct1, bL);
                         if (h == 0) st_lo[m] = st; else st_hi[m] = st;
                     }
                 }
@@ -422,8 +426,8 @@ blind_rotate_large_kernel(BlindRotateLargeArgs la) {
 #pragma unroll
                 for (int m = 0; m < R; m++) {
                     const size_t ja = CFG::aix((uint32_t)((tauA + CFG::TA * m) * P2 + b));
-                    a_lo[m] = ap[ja];
-                    a_hi[m] = ap[ja + P];
+                    a_lo[m] = EXTPROD ? 0 : ap[ja];     // EXTPROD: zeroed destination
+                    a_hi[m] = EXTPROD ? 0 : ap[ja + P];
                 }
                 fft_inverse<PA>(x, fca, areA, aimA, tauA);
 #pragma unroll

@@ -161,6 +161,82 @@ multibit_combine_kernel(MultiBitCombineArgs ca) {
     }
 }
 
+// ---- any other shape: two-kernel path only ------------------------------------------------------
+// The Fourier key of every blind-rotation variant is "the forward transform's output order", whatever that
+// is for its FFT plan.  Instead of deriving slot -> frequency per plan, the engine transforms the monomial X
+// once with the variant's own conversion kernel and reads the exponents off the result: slot s holds
+// zeta_s = w^{e_s} (w = e^{i pi / N}), so X^d has the value w^{d e_s mod 2N} there.  multibit_combine_generic_kernel
+// then prepares the GGSWs elementwise for any (N, k, levels), and the classic kernels' EXTPROD mode
+// (pbs_kernels.hip.h, pbs_large_kernels.hip.h) multiplies them in.
+struct MultiBitCombineGenericArgs {
+    const uint64_t* lwe_small;     // [count][n+1] (already offset to the sub-batch)
+    const double2* fbsk;           // [n/G][2^G][ggsw_elems]
+    const uint32_t* slot_exp;      // [P]
+    double2* combined;             // [count][n/G][ggsw_elems]
+    uint32_t n, logN, P, ggsw_elems, count;
+};
+
+template <int G>
+__global__ void __launch_bounds__(256)
+multibit_combine_generic_kernel(MultiBitCombineGenericArgs a) {
+    constexpr int SEL = (1 << G) - 1, EPT = 2, CHUNK = 8;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lo_bits = (a.logN + 1) / 2, hi_bits = a.logN + 1 - lo_bits, N = 1u << a.logN;
+    double2* root_lo = reinterpret_cast<double2*>(smem);
+    double2* root_hi = root_lo + (1u << lo_bits);
+    for (uint32_t e = threadIdx.x; e < (1u << lo_bits); e += 256) {
+        double sn, cs;
+        sincospi((double)e / (double)N, &sn, &cs);
+        root_lo[e] = make_double2(cs, sn);
+    }
+    for (uint32_t e = threadIdx.x; e < (1u << hi_bits); e += 256) {
+        double sn, cs;
+        sincospi((double)((size_t)e << lo_bits) / (double)N, &sn, &cs);
+        root_hi[e] = make_double2(cs, sn);
+    }
+    const uint32_t grp = blockIdx.x, groups = a.n / G;
+    const double2* gk = a.fbsk + (size_t)grp * (SEL + 1) * a.ggsw_elems;
+    uint32_t elem[EPT], expo[EPT];
+    double2 gv[SEL + 1][EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        elem[k] = (blockIdx.y * EPT + k) * 256 + threadIdx.x;
+        const bool live = elem[k] < a.ggsw_elems;
+        expo[k] = live ? a.slot_exp[elem[k] % a.P] : 0;
+#pragma unroll
+        for (int s = 0; s <= SEL; s++) gv[s][k] = live ? gk[(size_t)s * a.ggsw_elems + elem[k]] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    const uint32_t first = blockIdx.z * CHUNK, last = min(a.count, first + CHUNK);
+    for (uint32_t sample = first; sample < last; sample++) {
+        const uint64_t* lwe = a.lwe_small + (size_t)sample * (a.n + 1) + (size_t)grp * G;
+        cplx comb[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; k++) { comb[k].re = gv[0][k].x; comb[k].im = gv[0][k].y; }
+#pragma unroll
+        for (int s = 1; s <= SEL; s++) {
+            uint64_t sum = 0;
+#pragma unroll
+            for (int b = 0; b < G; b++)
+                if ((s >> (G - 1 - b)) & 1) sum += lwe[b];
+            const uint32_t d = modulus_switch(sum, (int)a.logN);
+#pragma unroll
+            for (int k = 0; k < EPT; k++) {
+                const uint32_t mi = (d * expo[k]) & (2u * N - 1u);
+                const double2 x = root_lo[mi & ((1u << lo_bits) - 1u)], y = root_hi[mi >> lo_bits];
+                const double mre = x.x * y.x - x.y * y.y, mim = x.x * y.y + x.y * y.x;
+                const double2 v = gv[s][k];
+                comb[k].re = fma(v.x, mre, fma(-v.y, mim, comb[k].re));
+                comb[k].im = fma(v.x, mim, fma(v.y, mre, comb[k].im));
+            }
+        }
+        double2* out = a.combined + ((size_t)sample * groups + grp) * a.ggsw_elems;
+#pragma unroll
+        for (int k = 0; k < EPT; k++)
+            if (elem[k] < a.ggsw_elems) out[elem[k]] = make_double2(comb[k].re, comb[k].im);
+    }
+}
+
 // PRE: args.fbsk points at multibit_combine_kernel's output for this batch instead of the Fourier key
 template <int LOGN, int LOGR, int K1, int G, bool PRE = false>
 __global__ void __launch_bounds__((BrMultiBitCfg<LOGN, LOGR, K1, G>::THREADS))

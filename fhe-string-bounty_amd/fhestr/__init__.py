@@ -99,6 +99,20 @@ PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS = Params(818, 1, 2048, 22, 1, 5
 PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS = Params(888, 1, 2048, 21, 1, 7, 2, 4, 4,
                                                           0.0000006125031601933181, 0.0000000000000003152931493498455,
                                                           "PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS", 3)
+# shortint/parameters/multi_bit.rs:96-113, :154-171 (N = 512, k = 3) and :134-152, :192-209 (N = 8192, two levels):
+# served by the two-kernel path (multibit_combine_generic_kernel + the classic kernels' EXTPROD mode)
+PARAM_MULTI_BIT_MESSAGE_1_CARRY_1_GROUP_2_KS_PBS = Params(764, 3, 512, 18, 1, 6, 2, 2, 2,
+                                                          0.000006025673585415336, 0.0000000000039666089171633006,
+                                                          "PARAM_MULTI_BIT_MESSAGE_1_CARRY_1_GROUP_2_KS_PBS", 2)
+PARAM_MULTI_BIT_MESSAGE_1_CARRY_1_GROUP_3_KS_PBS = Params(765, 3, 512, 18, 1, 6, 2, 2, 2,
+                                                          0.000005915594083804978, 0.0000000000039666089171633006,
+                                                          "PARAM_MULTI_BIT_MESSAGE_1_CARRY_1_GROUP_3_KS_PBS", 3)
+PARAM_MULTI_BIT_MESSAGE_3_CARRY_3_GROUP_2_KS_PBS = Params(922, 1, 8192, 14, 2, 4, 4, 8, 8,
+                                                          0.0000003272369292345697, 0.0000000000000000002168404344971009,
+                                                          "PARAM_MULTI_BIT_MESSAGE_3_CARRY_3_GROUP_2_KS_PBS", 2)
+PARAM_MULTI_BIT_MESSAGE_3_CARRY_3_GROUP_3_KS_PBS = Params(972, 1, 8192, 14, 2, 6, 3, 8, 8,
+                                                          0.00000013016688349592805, 0.0000000000000000002168404344971009,
+                                                          "PARAM_MULTI_BIT_MESSAGE_3_CARRY_3_GROUP_3_KS_PBS", 3)
 PARAM_MESSAGE_2_CARRY_1_KS_PBS = Params(742, 2, 1024, 23, 1, 4, 3, 4, 2,
                                         0.000007069849454709433, 0.00000000000000029403601535432533,
                                         "PARAM_MESSAGE_2_CARRY_1_KS_PBS")

@@ -121,6 +121,25 @@ PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS = Params(818, 1, 2048, 22, 1, 5
 PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS = Params(888, 1, 2048, 21, 1, 7, 2, 4, 4,
                                                           0.0000006125031601933181, 0.0000000000000003152931493498455,
                                                           "PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS")
+# shortint/parameters/multi_bit.rs:96-113, 154-171, 134-152, 192-209
+PARAM_MULTI_BIT_MESSAGE_1_CARRY_1_GROUP_2_KS_PBS = Params(764, 3, 512, 18, 1, 6, 2, 2, 2,
+                                                          0.000006025673585415336, 0.0000000000039666089171633006,
+                                                          "PARAM_MULTI_BIT_MESSAGE_1_CARRY_1_GROUP_2_KS_PBS")
+PARAM_MULTI_BIT_MESSAGE_1_CARRY_1_GROUP_3_KS_PBS = Params(765, 3, 512, 18, 1, 6, 2, 2, 2,
+                                                          0.000005915594083804978, 0.0000000000039666089171633006,
+                                                          "PARAM_MULTI_BIT_MESSAGE_1_CARRY_1_GROUP_3_KS_PBS")
+PARAM_MULTI_BIT_MESSAGE_3_CARRY_3_GROUP_2_KS_PBS = Params(922, 1, 8192, 14, 2, 4, 4, 8, 8,
+                                                          0.0000003272369292345697, 0.0000000000000000002168404344971009,
+                                                          "PARAM_MULTI_BIT_MESSAGE_3_CARRY_3_GROUP_2_KS_PBS")
+PARAM_MULTI_BIT_MESSAGE_3_CARRY_3_GROUP_3_KS_PBS = Params(972, 1, 8192, 14, 2, 6, 3, 8, 8,
+                                                          0.00000013016688349592805, 0.0000000000000000002168404344971009,
+                                                          "PARAM_MULTI_BIT_MESSAGE_3_CARRY_3_GROUP_3_KS_PBS")
+# the other multi-bit shapes with tiny n (two-kernel path of the engine)
+TOY_MULTI_BIT_N256_G3 = Params(15, 1, 256, 10, 2, 4, 4, 4, 4, 1e-12, 1e-15, "TOY_MULTI_BIT_N256_G3")
+TOY_MULTI_BIT_N128_K2 = Params(12, 2, 128, 12, 1, 3, 5, 2, 2, 1e-12, 1e-15, "TOY_MULTI_BIT_N128_K2_G2")
+TOY_MULTI_BIT_N512_K3_G3 = Params(9, 3, 512, 18, 1, 6, 2, 2, 2, 1e-12, 1e-15, "TOY_MULTI_BIT_N512_K3_G3")
+TOY_MULTI_BIT_N8192 = Params(8, 1, 8192, 14, 2, 4, 4, 8, 8, 1e-13, 1e-17, "TOY_MULTI_BIT_N8192_G2")
+TOY_MULTI_BIT_N8192_G3 = Params(9, 1, 8192, 14, 2, 6, 3, 8, 8, 1e-13, 1e-17, "TOY_MULTI_BIT_N8192_G3")
 TOY_MULTI_BIT_N2048 = Params(12, 1, 2048, 22, 1, 5, 3, 4, 4, 1e-13, 1e-17, "TOY_MULTI_BIT_N2048_G2")
 TOY_MULTI_BIT_N2048_G3 = Params(12, 1, 2048, 21, 1, 7, 2, 4, 4, 1e-13, 1e-17, "TOY_MULTI_BIT_N2048_G3")
 TOY_MULTI_BIT_N256 = Params(16, 1, 256, 10, 2, 4, 4, 4, 4, 1e-12, 1e-15, "TOY_MULTI_BIT_N256_G2")

@@ -54,7 +54,8 @@ def test_key_bits_grouping_factor_3():
     assert bits.tolist() == [0, 0, 0, 0, 0, 1, 0, 0]          # only selector 0b101
 
 
-@pytest.mark.parametrize("p", [O.TOY_MULTI_BIT_N256, TOY, TOY_G3], ids=lambda p: p.name)
+@pytest.mark.parametrize("p", [O.TOY_MULTI_BIT_N256, TOY, TOY_G3, O.TOY_MULTI_BIT_N128_K2, O.TOY_MULTI_BIT_N512_K3_G3],
+                         ids=lambda p: p.name)
 def test_oracle_multi_bit_pbs_decrypts(p):
     ck, sk = _keys(p)
     M = p.msg_mod * p.carry_mod
@@ -81,8 +82,14 @@ def test_product_client_generates_the_oracle_multi_bit_keys():
         assert np.array_equal(bsk, sk.bsk) and np.array_equal(ksk, sk.ksk)
 
 
+# every multi-bit parameter shape of shortint/parameters/multi_bit.rs: N = 2048 (fused kernel / prepared GGSWs),
+# N = 512 k = 3 and N = 8192 two levels (generic two-kernel path), plus toy shapes of the same kernels
+OTHER_SHAPES = [O.TOY_MULTI_BIT_N256, O.TOY_MULTI_BIT_N256_G3, O.TOY_MULTI_BIT_N128_K2, O.TOY_MULTI_BIT_N512_K3_G3,
+                O.TOY_MULTI_BIT_N8192, O.TOY_MULTI_BIT_N8192_G3, O.PARAM_MULTI_BIT_MESSAGE_1_CARRY_1_GROUP_3_KS_PBS]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("p", [TOY, REAL, TOY_G3, REAL_G3], ids=lambda p: p.name)
+@pytest.mark.parametrize("p", [TOY, REAL, TOY_G3, REAL_G3] + OTHER_SHAPES, ids=lambda p: p.name)
 def test_gpu_multi_bit_pbs_matches_oracle(p):
     import fhestr
     ck, sk = _keys(p)
@@ -111,6 +118,31 @@ def test_gpu_multi_bit_pbs_matches_oracle(p):
             + 2.0 ** (64 - p.pbs_base_log) * np.sqrt(p.n * (p.k * p.N / 2 + 1))
         for a, b in zip(got[:4], want):
             assert torus_distance(ck.decrypt_plaintext(a), ck.decrypt_plaintext(b)) < tol
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["PARAM_MULTI_BIT_MESSAGE_1_CARRY_1_GROUP_2_KS_PBS", "PARAM_MULTI_BIT_MESSAGE_1_CARRY_1_GROUP_3_KS_PBS",
+                                  "PARAM_MULTI_BIT_MESSAGE_3_CARRY_3_GROUP_2_KS_PBS", "PARAM_MULTI_BIT_MESSAGE_3_CARRY_3_GROUP_3_KS_PBS"])
+def test_gpu_multi_bit_reference_parameter_sets_decrypt(name):
+    """The reference's other multi-bit parameter sets as it defines them (shortint/parameters/multi_bit.rs:96-113,
+    154-171, 134-152, 192-209), keys generated on the device (0.9-1.3 GB for N = 8192): every message through a
+    random table decrypts right.  No oracle keys at this size: decrypt-level check with the product client."""
+    import fhestr
+    P = getattr(fhestr, name)
+    M = P.msg_mod * P.carry_mod
+    ck = fhestr.ClientKey(P, 0x4D42)
+    g, s = ck.secret_keys()
+    eng = fhestr.Engine(P, 0)
+    try:
+        eng.generate_keys(g, s, 0x4D42)
+        rng = np.random.default_rng(5)
+        table = rng.integers(0, M, size=M)
+        lut, _ = eng.generate_lookup_table(lambda x: int(table[x]))
+        msgs = np.arange(24) % M
+        out = eng.apply_lookup_table(ck.encrypt(msgs), np.full(len(msgs), lut, dtype=np.uint32))
+        assert np.array_equal(ck.decrypt(out), table[msgs])
     finally:
         eng.close()
 
