@@ -61,7 +61,7 @@ struct Engine {
     uint64_t *d_in = nullptr, *d_small = nullptr, *d_small2 = nullptr, *d_out = nullptr, *d_pool = nullptr;
     uint32_t* d_idx = nullptr;
     uint32_t* d_slot_exp = nullptr;   // multi-bit two-kernel path: exponent of w = e^{i pi / N} each Fourier slot evaluates at
-    size_t multibit_workspace_cap = (size_t)8 << 30;   // prepared GGSWs kept at once (larger batches run in sub-batches)
+    size_t multibit_workspace_cap = 0;   // bytes of prepared GGSWs kept at once, larger batches run in sub-batches (0 = from free memory)
     void* d_meta = nullptr;
     void* d_ws = nullptr;      // per-LWE HBM workspace of the large-N blind rotation
     size_t cap_ws = 0;

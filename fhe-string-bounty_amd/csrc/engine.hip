@@ -565,7 +565,13 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
         // products per LWE; sub-batches keep the prepared GGSWs within a fixed workspace
         const size_t groups = p.n / p.grouping_factor, per_lwe = groups * v->combined_bytes;
         const size_t rot_ws = v->large ? v->ws_bytes : 0;
-        const uint32_t sub_max = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, multibit_workspace_cap / (per_lwe + rot_ws)));
+        size_t cap = multibit_workspace_cap;
+        if (cap == 0) {       // automatic: half of what is free now (plus what the workspace already holds), at most 64 GB
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            cap = std::min<size_t>((size_t)64 << 30, (free_b + cap_ws) / 2);
+        }
+        const uint32_t sub_max = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, cap / (per_lwe + rot_ws)));
         if (ensure(&d_ws, &cap_ws, (size_t)sub_max * (per_lwe + rot_ws))) return 1;
         unsigned char* rot_base = reinterpret_cast<unsigned char*>(d_ws) + (size_t)sub_max * per_lwe;
         uint32_t logN = 0;
