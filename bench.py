@@ -71,7 +71,20 @@ def cpu_baseline(P, bsk, ksk, cts, lut_tables, lut_sel):
     L.orc_ks_pbs_batch(C.byref(op.c()), ksk, fbsk.ctypes.data_as(C.c_void_p), None, 0, cts,
                        idx.ctypes.data_as(C.c_void_p), luts, out, cts.shape[0], cores)
     dt = time.perf_counter() - t0
+    # also one thread alone (ms per KS+PBS), and which CPU this was
+    one = np.zeros_like(cts[:8])
+    t0 = time.perf_counter()
+    L.orc_ks_pbs_batch(C.byref(op.c()), ksk, fbsk.ctypes.data_as(C.c_void_p), None, 0, np.ascontiguousarray(cts[:8]),
+                       idx[:8].ctypes.data_as(C.c_void_p), luts, one, 8, 1)
+    single_ms = (time.perf_counter() - t0) / 8 * 1e3
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
+    except OSError:
+        pass
     return {"value": cts.shape[0] / dt, "unit": "PBS/s", "cores": cores, "kind": "port",
+            "single_thread_ms_per_pbs": single_ms, "cpu_model": model, "nproc": os.cpu_count(),
             "sample": f"the same {cts.shape[0]}-LWE batch, KS+PBS per LWE, {cores} host threads over LWEs "
                       f"(oracle/tfhe_oracle.c, gcc -O3; reference publishes 16.6 ms/PBS/core on Xeon 8375C)",
             "seconds": dt}, out

@@ -310,6 +310,47 @@ struct FftTwiddleTable {
     }
 };
 
+// Pass 0's twiddles in VGPRs, the later passes' (few distinct values: n_tp shrinks by the radix every pass) in an
+// LDS table -- for plans with many passes, where NTW * R complex constants per thread push the kernel into
+// spilling (N = 4096: five radix-4 passes, 80 VGPRs).  Table layout as FftTwiddleTable, without pass 0.
+template <class PL>
+struct FftHybridConsts {
+    using TBL = FftTwiddleTable<PL>;
+    static constexpr int ENTRIES = TBL::ENTRIES - TBL::off(1);
+    cplx tw0[PL::R];
+    const double2* base;     // entries of passes 1 .. NTW-1
+    int tau;
+    __device__ __forceinline__ static void fill(double2* b, int tid, int nthreads) {
+#pragma unroll
+        for (int s = 1; s < PL::NTW; s++) {
+            const int ntp = TBL::n_tp(s);
+            for (int e = tid; e < PL::R * ntp; e += nthreads) {
+                const int q = e / ntp, tp = e % ntp;
+                double sn, cs;
+                sincospi(-2.0 * (double)(q * tp) / (double)(1 << PL::log_S(s)), &sn, &cs);
+                b[TBL::off(s) - TBL::off(1) + e] = make_double2(cs, sn);
+            }
+        }
+    }
+    __device__ __forceinline__ void init(const double2* table, int tau_) {
+        base = table;
+        tau = tau_;
+        const int tp = tau_ & (TBL::n_tp(0) - 1);
+#pragma unroll
+        for (int q = 0; q < PL::R; q++) {
+            double sn, cs;
+            sincospi(-2.0 * (double)(q * tp) / (double)(1 << PL::log_S(0)), &sn, &cs);
+            tw0[q].re = cs; tw0[q].im = sn;
+        }
+    }
+    __device__ __forceinline__ cplx get(int s, int q) const {
+        if (s == 0) return tw0[q];
+        const double2 v = base[TBL::off(s) - TBL::off(1) + q * TBL::n_tp(s) + (tau & (TBL::n_tp(s) - 1))];
+        cplx r; r.re = v.x; r.im = v.y;
+        return r;
+    }
+};
+
 template <class PL>
 __device__ __forceinline__ void fft_init_consts(FftConsts<PL>& c, int tau) {
 #pragma unroll
@@ -672,14 +713,14 @@ __device__ __forceinline__ void pass_store(const cplx* x, int s, double* re, dou
         }
     }
 }
-template <class PL, bool INV>
-__device__ __forceinline__ void pass_compute(cplx* x, int s, const FftConsts<PL>& c) {
+template <class PL, bool INV, class C>
+__device__ __forceinline__ void pass_compute(cplx* x, int s, const C& c) {
     constexpr int R = PL::R;
     const int lr = PL::log_radix(s);
     const int rr = 1 << lr;
     if (INV && s < PL::NTW) {
 #pragma unroll
-        for (int q = 1; q < R; q++) x[q] = cmul_conj(x[q], c.tw[s][q]);
+        for (int q = 1; q < R; q++) x[q] = cmul_conj(x[q], c.get(s, q));
     }
     if (lr == PL::LOGR) {
         small_dft<R, INV>(x);
@@ -689,7 +730,7 @@ __device__ __forceinline__ void pass_compute(cplx* x, int s, const FftConsts<PL>
     }
     if (!INV && s < PL::NTW) {
 #pragma unroll
-        for (int q = 1; q < R; q++) x[q] = cmul(x[q], c.tw[s][q]);
+        for (int q = 1; q < R; q++) x[q] = cmul(x[q], c.get(s, q));
     }
 }
 __device__ __forceinline__ bool pass_sync_is_wave_local(int log_S_next) { return (1 << log_S_next) <= 64; }
@@ -698,8 +739,8 @@ __device__ __forceinline__ bool pass_sync_is_wave_local(int log_S_next) { return
 // workgroup barrier are done for all polynomials at once; wave-local exchanges are software
 // pipelined: polynomial p's store + the next pass's load are issued before polynomial p+1's
 // butterflies, so the LDS round trip of one stream hides behind the VALU work of the other.
-template <class PL, int NPOLY>
-__device__ __forceinline__ void fft_forward_multi(cplx (*x)[PL::R], const FftConsts<PL>& c, double* re0,
+template <class PL, int NPOLY, class C>
+__device__ __forceinline__ void fft_forward_multi(cplx (*x)[PL::R], const C& c, double* re0,
                                                   int poly_stride, int im_off, int tau) {
     if constexpr (PL::SWAP) {
         swap10_forward<NPOLY>(x, c, re0, poly_stride, im_off, tau);
@@ -730,8 +771,8 @@ __device__ __forceinline__ void fft_forward_multi(cplx (*x)[PL::R], const FftCon
     }
 }
 
-template <class PL, int NPOLY>
-__device__ __forceinline__ void fft_inverse_multi(cplx (*x)[PL::R], const FftConsts<PL>& c, double* re0,
+template <class PL, int NPOLY, class C>
+__device__ __forceinline__ void fft_inverse_multi(cplx (*x)[PL::R], const C& c, double* re0,
                                                   int poly_stride, int im_off, int tau) {
     if constexpr (PL::SWAP) {
         swap10_inverse<NPOLY>(x, c, re0, poly_stride, im_off, tau);

@@ -21,6 +21,7 @@
 //                    one 16-byte element per lane per load -> fully coalesced dwordx4 streams)
 //   big LWE batch    [B][kN+1] u64
 #pragma once
+#include <type_traits>
 #include "negacyclic_fft.hip.h"
 
 namespace fhe {
@@ -590,8 +591,12 @@ struct BrWideCfg {
     static constexpr int THREADS = T;
     static constexpr int PLANE = P + 2;
     static constexpr int GROUP_SLOTS = 2 * P + 4;
-    static constexpr size_t LDS_FIXED = (size_t)K1 * N * 8 /*acc*/ + (size_t)K1 * GROUP_SLOTS * 8 /*x*/;
+    // plans with more than four passes keep only pass 0's twiddles in VGPRs (FftHybridConsts)
+    static constexpr bool TW_IN_LDS = !PL::SWAP && PL::NTW > 4;
+    static constexpr size_t LDS_TW = TW_IN_LDS ? (size_t)FftHybridConsts<PL>::ENTRIES * 16 : 0;
+    static constexpr size_t LDS_FIXED = (size_t)K1 * N * 8 /*acc*/ + (size_t)K1 * GROUP_SLOTS * 8 /*x*/ + LDS_TW;
     // keep the whole Fourier GGSW of a step in VGPRs only when it is small
+    // (also where the twiddles moved to LDS: without the prefetch N = 4096 has no spills but runs 9.5 instead of 7.8 ms)
     static constexpr bool PREFETCH_ALL = K1 * K1 * R * 4 <= 64;
 };
 
@@ -604,7 +609,8 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t* lds_acc = reinterpret_cast<uint64_t*>(smem);                       // [K1][N]
     double* lds_x = reinterpret_cast<double*>(smem + (size_t)K1 * N * 8);        // [K1][GROUP_SLOTS]
-    uint32_t* lds_d = reinterpret_cast<uint32_t*>(lds_x + (size_t)K1 * CFG::GROUP_SLOTS);   // [n]
+    double2* lds_tw = reinterpret_cast<double2*>(lds_x + (size_t)K1 * CFG::GROUP_SLOTS);    // [LDS_TW / 16]
+    uint32_t* lds_d = reinterpret_cast<uint32_t*>(lds_tw + CFG::LDS_TW / 16);               // [n]
 
     const int tau = threadIdx.x;
     const uint32_t sample = blockIdx.x;
@@ -621,8 +627,13 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
         lds_d[i] = a == 0 ? 0xFFFFFFFFu : modulus_switch(a, LOGN);
     }
 
-    FftConsts<PL> fc;
-    fft_init_consts<PL>(fc, tau);
+    typename std::conditional<CFG::TW_IN_LDS, FftHybridConsts<PL>, FftConsts<PL>>::type fc;
+    if constexpr (CFG::TW_IN_LDS) {
+        FftHybridConsts<PL>::fill(lds_tw, threadIdx.x, CFG::THREADS);      // visible after the barrier below
+        fc.init(lds_tw, tau);
+    } else {
+        fft_init_consts<PL>(fc, tau);
+    }
     cplx twist[R], twbias[R];
 #pragma unroll
     for (int m = 0; m < R; m++) {
