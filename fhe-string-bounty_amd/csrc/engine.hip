@@ -20,6 +20,7 @@
 #include "pbs_kernels.hip.h"
 #include "pbs_large_kernels.hip.h"
 #include "pbs_multibit_kernels.hip.h"
+#include "pbs_seq_kernels.hip.h"
 
 namespace fhe {
 
@@ -95,6 +96,7 @@ BrVariant make_large_variant() {
     using CFG = BrLargeCfg<LOGN, K1, L>;
     BrVariant v;
     v.logN = LOGN; v.k1 = K1; v.L = L; v.logR = 3; v.wide = false; v.large = true;
+    v.lds_per_n = 0;
     v.threads = CFG::THREADS;
     v.convert_threads = CFG::THREADS;
     v.lds_bytes = CFG::LDS_BYTES;
@@ -103,6 +105,24 @@ BrVariant make_large_variant() {
     v.convert_ws = (size_t)CFG::P * 16;
     v.rotate_fn = reinterpret_cast<const void*>(&blind_rotate_large_kernel<LOGN, K1, L>);
     v.convert_fn = reinterpret_cast<const void*>(&bsk_convert_large_kernel<LOGN, K1, L>);
+    return v;
+}
+
+// N = 8192: transforms in LDS one polynomial at a time, accumulator in a cache-resident workspace (pbs_seq_kernels.hip.h)
+template <int LOGN, int K1, int L>
+BrVariant make_seq_variant() {
+    using CFG = BrSeqCfg<LOGN, K1, L>;
+    BrVariant v;
+    v.logN = LOGN; v.k1 = K1; v.L = L; v.logR = 3; v.wide = false; v.large = true;
+    v.lds_per_n = 4;
+    v.threads = CFG::THREADS;
+    v.convert_threads = CFG::THREADS;
+    v.lds_bytes = CFG::LDS_FIXED;
+    v.convert_lds = CFG::LDS_CONVERT;
+    v.ws_bytes = CFG::WS_BYTES;
+    v.convert_ws = 16;
+    v.rotate_fn = reinterpret_cast<const void*>(&blind_rotate_seq_kernel<LOGN, K1, L>);
+    v.convert_fn = reinterpret_cast<const void*>(&bsk_convert_seq_kernel<LOGN, K1, L>);
     return v;
 }
 
@@ -138,6 +158,18 @@ BrVariant make_multibit_generic_variant(int G) {
 }
 
 template <int LOGN, int K1, int L>
+BrVariant make_multibit_seq_variant(int G) {
+    BrVariant v = make_seq_variant<LOGN, K1, L>();
+    v.grouping = G;
+    v.extprod_fn = reinterpret_cast<const void*>(&blind_rotate_seq_kernel<LOGN, K1, L, true>);
+    v.rotate_fn = v.extprod_fn;
+    v.combine_generic_fn = G == 2 ? reinterpret_cast<const void*>(&multibit_combine_generic_kernel<2>)
+                                  : reinterpret_cast<const void*>(&multibit_combine_generic_kernel<3>);
+    v.combined_bytes = (size_t)L * K1 * K1 * (size_t)(1 << (LOGN - 1)) * 16;
+    return v;
+}
+
+template <int LOGN, int K1, int L>
 BrVariant make_multibit_large_variant(int G) {
     BrVariant v = make_large_variant<LOGN, K1, L>();
     v.grouping = G;
@@ -161,7 +193,7 @@ static const std::vector<BrVariant>& variants() {
         // PARAM_MULTI_BIT_MESSAGE_1_CARRY_1_GROUP_{2,3}_KS_PBS (N = 512, k = 3) and
         // PARAM_MULTI_BIT_MESSAGE_3_CARRY_3_GROUP_{2,3}_KS_PBS (N = 8192, two levels): two-kernel path
         make_multibit_generic_variant<9, 2, 4, 1>(2), make_multibit_generic_variant<9, 2, 4, 1>(3),
-        make_multibit_large_variant<13, 2, 2>(2), make_multibit_large_variant<13, 2, 2>(3),
+        make_multibit_seq_variant<13, 2, 2>(2), make_multibit_seq_variant<13, 2, 2>(3),
         // toy shapes of the multi-bit tests (N = 256, k = 1, two levels; N = 128, k = 2)
         make_multibit_generic_variant<8, 2, 2, 2>(2), make_multibit_generic_variant<8, 2, 2, 2>(3),
         make_multibit_generic_variant<7, 2, 3, 1>(2), make_multibit_generic_variant<7, 2, 3, 1>(3),
@@ -178,7 +210,7 @@ static const std::vector<BrVariant>& variants() {
         make_variant<9, 2, 3, 2>(),                                  // N = 512, k = 2, 2 levels (2_CARRY_0)
         make_wide_variant<12, 2, 2, 1>(), make_wide_variant<12, 2, 2, 2>(),   // N = 4096 (2_CARRY_3 ..., 1_CARRY_4)
         // polynomial sizes beyond the LDS: four-step FFT through an HBM workspace
-        make_large_variant<13, 2, 1>(), make_large_variant<13, 2, 2>(),       // N = 8192  (5_CARRY_1 ..., 3_CARRY_3 ...)
+        make_seq_variant<13, 2, 1>(), make_seq_variant<13, 2, 2>(),           // N = 8192  (5_CARRY_1 ..., 3_CARRY_3 ...)
         make_large_variant<14, 2, 2>(),                                       // N = 16384 (3_CARRY_4 ...)
         make_large_variant<15, 2, 2>(),                                       // N = 32768 (4_CARRY_4 ...)
         make_large_variant<14, 2, 3>(), make_large_variant<15, 2, 3>(),       // 3 levels of base 2^11 (1_CARRY_6, 3_CARRY_5 ...)
@@ -593,7 +625,8 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
             if (v->large) {
                 BlindRotateLargeArgs la{b, rot_base};
                 void* largs[] = {(void*)&la};
-                HIP_TRY(hipLaunchKernel(v->extprod_fn, dim3(sub), dim3(v->threads), largs, v->lds_bytes, stream));
+                HIP_TRY(hipLaunchKernel(v->extprod_fn, dim3(sub), dim3(v->threads), largs,
+                                        v->lds_bytes + (size_t)p.n * v->lds_per_n, stream));
             } else {
                 void* bargs[] = {(void*)&b};
                 HIP_TRY(hipLaunchKernel(v->extprod_fn, dim3(sub), dim3(v->threads), bargs,
@@ -606,7 +639,8 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
         if (ensure(&d_ws, &cap_ws, (size_t)count * v->ws_bytes)) return 1;
         BlindRotateLargeArgs la{a, reinterpret_cast<unsigned char*>(d_ws)};
         void* largs[] = {(void*)&la};
-        HIP_TRY(hipLaunchKernel(v->rotate_fn, dim3(count), dim3(v->threads), largs, v->lds_bytes, stream));
+        HIP_TRY(hipLaunchKernel(v->rotate_fn, dim3(count), dim3(v->threads), largs,
+                                v->lds_bytes + (size_t)p.n * v->lds_per_n, stream));
         return 0;
     }
     HIP_TRY(hipLaunchKernel(v->rotate_fn, dim3(count), dim3(v->threads), args,

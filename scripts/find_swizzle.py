@@ -77,6 +77,9 @@ def search(logp, logr, tries=2_000_00, seed=1):
 
 
 if __name__ == "__main__":
-    for logp, logr in [(10, 2), (10, 3), (10, 4), (9, 3), (9, 2), (8, 2), (11, 3), (11, 4)]:
+    pairs = [(10, 2), (10, 3), (10, 4), (9, 3), (9, 2), (8, 2), (11, 3), (11, 4)]
+    if len(sys.argv) > 2:           # find_swizzle.py LOGP LOGR
+        pairs = [(int(sys.argv[1]), int(sys.argv[2]))]
+    for logp, logr in pairs:
         cols = search(logp, logr)
         print(f"LOGP={logp} LOGR={logr}: {cols}")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """KS+PBS kernel time of every reference parameter set (tests/golden/reference_parameter_sets.json) at one batch size:
 
-    python3 scripts/param_sweep.py [B [N]]      (default 256, every polynomial size; GPU box)
+    python3 scripts/param_sweep.py [B [N [name-part]]]      (default 256, every polynomial size and set; GPU box)
 
 Device-generated keys, decrypt-checked; prints keyswitch / blind-rotation ms (HIP events in the engine) and PBS/s."""
 import json
@@ -17,10 +17,11 @@ import fhestr  # noqa: E402
 TABLE = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_parameter_sets.json")))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ONLY_N = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+ONLY_NAME = sys.argv[3] if len(sys.argv) > 3 else ""
 rows = []
 for name in sorted(TABLE, key=lambda k: (TABLE[k]["polynomial_size"], k)):
     r = TABLE[name]
-    if r["encryption_key_choice"] == "Small" or (ONLY_N and r["polynomial_size"] != ONLY_N):
+    if r["encryption_key_choice"] == "Small" or (ONLY_N and r["polynomial_size"] != ONLY_N) or ONLY_NAME not in name:
         continue
     P = fhestr.Params(r["lwe_dimension"], r["glwe_dimension"], r["polynomial_size"], r["pbs_base_log"], r["pbs_level"],
                       r["ks_base_log"], r["ks_level"], r["message_modulus"], r["carry_modulus"],

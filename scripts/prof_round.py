@@ -43,7 +43,7 @@ def run(cmd, log):
 
 
 def short(name):
-    for k in ("blind_rotate_large_kernel", "blind_rotate_wide_kernel", "blind_rotate_multibit_kernel",
+    for k in ("blind_rotate_seq_kernel", "blind_rotate_large_kernel", "blind_rotate_wide_kernel", "blind_rotate_multibit_kernel",
               "blind_rotate_kernel", "keyswitch_dot4_kernel", "keyswitch_kernel", "lincomb_kernel"):
         if k in name:
             return k
@@ -55,7 +55,11 @@ def main():
     p44 = "--p44" in sys.argv
     out = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     os.makedirs(out, exist_ok=True)
-    if p44:
+    custom = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--prog=")), None)
+    if custom:         # any other program of this repo, e.g. --prog="python3 scripts/param_sweep.py 256 8192 5_CARRY_1"
+        prog = custom.split()
+        stats_prog = prog
+    elif p44:
         prog = ["python3", "scripts/p44_prof.py"]
         stats_prog = prog
     else:
