@@ -97,10 +97,26 @@ blind_rotate_seq_kernel(BlindRotateLargeArgs la) {
     const uint64_t* lwe = args.lwe_small + (size_t)sample * (n + 1);
     const uint64_t* lut = args.luts + (size_t)(args.lut_idx ? args.lut_idx[sample] : 0) * K1 * N;
     uint64_t* ws_acc = reinterpret_cast<uint64_t*>(la.workspace + (size_t)sample * CFG::WS_BYTES);   // [K1 - LDS_POLYS][N]
-    // polynomial p of the accumulator (p is a compile-time constant wherever this is called in the step)
+    // Polynomial p of the accumulator (p is a compile-time constant wherever these are called in the step): LDS, or
+    // the workspace through a raw buffer resource -- byte offset = one VGPR + a scalar, no 64-bit address pairs
+    // (the first version spent ~60 spilled dwords per step on precomputed global addresses).
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    const auto ws_rsrc = __builtin_amdgcn_make_buffer_rsrc(ws_acc, 0, (int)(CFG::WS_BYTES > 0 ? CFG::WS_BYTES : 8), 0x00020000);
+    auto acc_load = [&](int p, uint32_t voff, uint32_t soff) -> uint64_t {
+        if (p < CFG::LDS_POLYS) return lds_acc[(size_t)p * N + ((voff + soff) >> 3)];
+        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(ws_rsrc, (int)voff, (int)(soff + (uint32_t)(p - CFG::LDS_POLYS) * N * 8u), 0);
+        return ((uint64_t)v.y << 32) | v.x;
+    };
+    auto acc_store = [&](int p, uint32_t voff, uint32_t soff, uint64_t val) {
+        if (p < CFG::LDS_POLYS) { lds_acc[(size_t)p * N + ((voff + soff) >> 3)] = val; return; }
+        u32x2_t v;
+        v.x = (uint32_t)val; v.y = (uint32_t)(val >> 32);
+        __builtin_amdgcn_raw_buffer_store_b64(v, ws_rsrc, (int)voff, (int)(soff + (uint32_t)(p - CFG::LDS_POLYS) * N * 8u), 0);
+    };
     auto acc_poly = [&](int p) -> uint64_t* {
         return p < CFG::LDS_POLYS ? lds_acc + (size_t)p * N : ws_acc + (size_t)(p - CFG::LDS_POLYS) * N;
     };
+    const uint32_t tau8 = (uint32_t)tau * 8u;
     const uint32_t bL = args.base_log * L;
 
     for (uint32_t i = threadIdx.x; i < steps; i += CFG::THREADS) {
@@ -145,6 +161,7 @@ blind_rotate_seq_kernel(BlindRotateLargeArgs la) {
     const double2* fbsk = reinterpret_cast<const double2*>(args.fbsk);
     constexpr size_t GGSW_ELEMS = (size_t)L * K1 * K1 * P;
     if constexpr (EXTPROD) fbsk += (size_t)sample * steps * GGSW_ELEMS;
+    const auto key_rsrc = key_resource(reinterpret_cast<const double*>(fbsk), (size_t)steps * GGSW_ELEMS * 16);
 
     uint32_t d_next = lds_d[0];
     for (uint32_t i = 0; i < steps; i++) {
@@ -154,23 +171,22 @@ blind_rotate_seq_kernel(BlindRotateLargeArgs la) {
         asm volatile("" : "+v"(twist0.re), "+v"(twist0.im));
         const uint32_t rem = d & (N - 1);
         const bool odd = (d >> LOGN) & 1;
-        const double2* bk0 = fbsk + (size_t)i * GGSW_ELEMS;
-
         cplx outf[K1][R];
 #pragma unroll
         for (int r = 0; r < K1; r++) {
             // ct1 = acc_r * X^d - acc_r (polynomial_algorithms.rs:463-489), decomposition state per coefficient
             using state_t = typename std::conditional<(L >= 3), uint64_t, uint32_t>::type;
             state_t st_lo[R], st_hi[R];
-            const uint64_t* ap = acc_poly(r);
+            const uint32_t rem8 = rem * 8u;
 #pragma unroll
             for (int m = 0; m < R; m++) {
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
+                    const uint32_t c8 = (uint32_t)(m * T + h * P) * 8u;           // j = tau + T m + h P
                     const uint32_t j = (uint32_t)PL::point(tau, m) + h * P;
-                    uint64_t ct1 = ap[j];
+                    uint64_t ct1 = acc_load(r, tau8, c8);
                     if constexpr (!EXTPROD) {
-                        uint64_t v = ap[(j - rem) & (N - 1)];
+                        uint64_t v = acc_load(r, (tau8 + c8 - rem8) & (8u * N - 1u), 0);
                         v = ((j < rem) != odd) ? (0 - v) : v;
                         ct1 = v - ct1;
                     }
@@ -190,7 +206,8 @@ blind_rotate_seq_kernel(BlindRotateLargeArgs la) {
                 for (int col = 0; col < K1; col++)
 #pragma unroll
                     for (int rho = 0; rho < R; rho++)
-                        bv[col][rho] = bk0[(((size_t)lvl_idx * K1 + r) * K1 + col) * P + rho * T + tau];
+                        bv[col][rho] = key_load(key_rsrc, tau8 * 2u,
+                                                (uint32_t)((i * GGSW_ELEMS + (((size_t)lvl_idx * K1 + r) * K1 + col) * P + rho * T) * 16));
                 cplx x[R];
 #pragma unroll
                 for (int m = 0; m < R; m++) {
@@ -225,20 +242,19 @@ blind_rotate_seq_kernel(BlindRotateLargeArgs la) {
         // back to the standard domain and accumulate (fft/mod.rs:285-304, 539-557; 1/(N/2) lives in the key)
 #pragma unroll
         for (int col = 0; col < K1; col++) {
-            uint64_t* ap = acc_poly(col);
             uint64_t a_lo[R], a_hi[R];       // requested before the transform
 #pragma unroll
             for (int m = 0; m < R; m++) {
-                a_lo[m] = EXTPROD ? 0 : ap[PL::point(tau, m)];
-                a_hi[m] = EXTPROD ? 0 : ap[PL::point(tau, m) + P];
+                a_lo[m] = EXTPROD ? 0 : acc_load(col, tau8, (uint32_t)(m * T) * 8u);
+                a_hi[m] = EXTPROD ? 0 : acc_load(col, tau8, (uint32_t)(m * T + P) * 8u);
             }
             __syncthreads();
             fft_inverse<PL>(outf[col], fc, re, im, tau);
 #pragma unroll
             for (int m = 0; m < R; m++) {
                 const cplx t = cmul_conj(outf[col][m], twist_of(m));
-                ap[PL::point(tau, m)] = a_lo[m] + from_torus(t.re);
-                ap[PL::point(tau, m) + P] = a_hi[m] + from_torus(t.im);
+                acc_store(col, tau8, (uint32_t)(m * T) * 8u, a_lo[m] + from_torus(t.re));
+                acc_store(col, tau8, (uint32_t)(m * T + P) * 8u, a_hi[m] + from_torus(t.im));
             }
         }
         __syncthreads();     // the accumulator update is visible to the next step's rotated reads (same CU, same L1)
