@@ -1,6 +1,6 @@
 // pbs_large_kernels.hip.h -- blind rotation for polynomial sizes whose accumulator and spectra do
-// not fit the 160 KB LDS of a CU (N >= 8192: PARAM_MESSAGE_3_CARRY_3 N = 8192, PARAM_MESSAGE_4_CARRY_4
-// N = 32768, shortint/parameters/mod.rs:853-867,1063-1077).
+// not fit the 160 KB LDS of a CU (N >= 16384: PARAM_MESSAGE_4_CARRY_4 N = 32768, shortint/parameters/mod.rs:1063-1077;
+// N = 8192 is instantiable here too but runs on pbs_seq_kernels.hip.h since round 2).
 //
 // Same algorithm as pbs_kernels.hip.h (fft64/crypto/bootstrap.rs:242-364, ggsw.rs:477-598), other
 // data placement: one workgroup per LWE keeps its accumulator (k+1)*N u64 and two spectrum buffers
