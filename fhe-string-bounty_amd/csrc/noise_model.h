@@ -64,7 +64,10 @@ inline NoiseModel noise_model(const fhe_params_t& p) {
     const double N = p.N, k = p.k, n = p.n, l = p.pbs_level, lk = p.ks_level;
     const double B = ldexp(1.0, (int)p.pbs_base_log), Bk = ldexp(1.0, (int)p.ks_base_log);
     const double steps = p.grouping_factor > 1 ? n / p.grouping_factor : n;
-    m.v_pbs_ggsw = steps * l * (k + 1) * N * (B * B + 2) / 12.0 * p.glwe_std * p.glwe_std;
+    // multi-bit: a step multiplies by G0 + sum_sel G_sel X^{d_sel}, the sum of 2^g independent GGSW encryptions
+    // (lwe_multi_bit_programmable_bootstrapping.rs:18-83), so its key-noise term carries 2^g variances
+    const double ggsw_per_step = p.grouping_factor > 1 ? ldexp(1.0, (int)p.grouping_factor) : 1.0;
+    m.v_pbs_ggsw = steps * ggsw_per_step * l * (k + 1) * N * (B * B + 2) / 12.0 * p.glwe_std * p.glwe_std;
     m.v_pbs_round = steps * (1.0 + k * N / 2.0) / (24.0 * pow(B, 2 * l)) + steps * k * N / 32.0 * ldexp(1.0, -128);
     m.v_pbs_fft = steps * kFftNoiseConstant * ldexp(1.0, -106) * l * (k + 1) * N * (B * B / 144.0) * (1.0 + k * N / 2.0);
     m.v_pbs = m.v_pbs_ggsw + m.v_pbs_round + m.v_pbs_fft;
