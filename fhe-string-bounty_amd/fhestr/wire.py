@@ -39,6 +39,18 @@ def _sigs():
             ("fhe_wire_read_keyswitch_key", [PP, vp, sz, vp, szp]),
             ("fhe_wire_write_bootstrap_key", [PP, vp, vp, sz, szp]),
             ("fhe_wire_read_bootstrap_key", [PP, vp, sz, vp, szp]),
+            ("fhe_aes128_encrypt_block", [vp, vp, vp]),
+            ("fhe_seeded_mask_words", [vp, vp, sz]),
+            ("fhe_seeded_decompress_keyswitch_key", [PP, vp, vp, vp]),
+            ("fhe_seeded_decompress_bootstrap_key", [PP, vp, vp, vp]),
+            ("fhe_seeded_split_keyswitch_key", [PP, vp, vp]),
+            ("fhe_seeded_split_bootstrap_key", [PP, vp, vp]),
+            ("fhe_wire_write_seeded_keyswitch_key", [PP, vp, vp, vp, sz, szp]),
+            ("fhe_wire_read_seeded_keyswitch_key", [PP, vp, sz, vp, vp, szp]),
+            ("fhe_wire_write_seeded_bootstrap_key", [PP, vp, vp, vp, sz, szp]),
+            ("fhe_wire_read_seeded_bootstrap_key", [PP, vp, sz, vp, vp, szp]),
+            ("fhe_wire_write_multi_bit_bootstrap_key", [PP, vp, vp, sz, szp]),
+            ("fhe_wire_read_multi_bit_bootstrap_key", [PP, vp, sz, vp, szp]),
             ("fhe_wire_write_shortint_ciphertext", [vp, sz, C.POINTER(_Meta), C.c_int, vp, sz, szp]),
             ("fhe_wire_read_shortint_ciphertext", [vp, sz, C.c_int, C.c_uint64, vp, sz, szp, C.POINTER(_Meta), szp])):
         fn = getattr(L, name)
@@ -115,3 +127,103 @@ def read_shortint_ciphertext(data: bytes, safe: bool = False, size_limit: int = 
     _check(_sigs().fhe_wire_read_shortint_ciphertext(_in(data), len(data), int(safe), size_limit, _ptr(ct), ct.size,
                                                      C.byref(size), C.byref(m), C.byref(used)))
     return ct[:size.value].copy(), ShortintMeta(m.degree, m.noise_level, m.message_modulus, m.carry_modulus, m.pbs_order), used.value
+
+
+# ---- seeded ("compressed") server keys: shortint/server_key/compressed.rs; csrc/seeded_keys.cpp -------------------
+
+def _seed16(seed) -> "C.Array":
+    """128-bit compression seed: 16 bytes, or an int (the reference's Seed(u128), native = little endian)."""
+    b = seed.to_bytes(16, "little") if isinstance(seed, int) else bytes(seed)
+    if len(b) != 16:
+        raise FheError("compression seed must be 16 bytes")
+    return (C.c_uint8 * 16).from_buffer_copy(b)
+
+
+def ksk_bodies_len(params: Params) -> int:
+    return params.k * params.N * params.ks_level
+
+
+def bsk_bodies_len(params: Params) -> int:
+    return params.n_ggsw * params.pbs_level * (params.k + 1) * params.N
+
+
+def aes128_encrypt_block(key: bytes, block: bytes) -> bytes:
+    out = (C.c_uint8 * 16)()
+    _check(_sigs().fhe_aes128_encrypt_block(_in(key), _in(block), out))
+    return bytes(out)
+
+
+def seeded_mask_words(seed, count: int) -> np.ndarray:
+    """The first `count` u64 a MaskRandomGenerator::new(Seed(seed)) draws."""
+    out = np.zeros(count, dtype=np.uint64)
+    _check(_sigs().fhe_seeded_mask_words(_seed16(seed), _ptr(out), count))
+    return out
+
+
+def decompress_keyswitch_key(params: Params, seed, bodies) -> np.ndarray:
+    bodies = _u64(bodies)
+    if bodies.size != ksk_bodies_len(params):
+        raise FheError("seeded keyswitch key: body count mismatch")
+    ksk = np.zeros(params.ksk_len, dtype=np.uint64)
+    _check(_sigs().fhe_seeded_decompress_keyswitch_key(C.byref(params.c()), _seed16(seed), _ptr(bodies), _ptr(ksk)))
+    return ksk
+
+
+def decompress_bootstrap_key(params: Params, seed, bodies) -> np.ndarray:
+    bodies = _u64(bodies)
+    if bodies.size != bsk_bodies_len(params):
+        raise FheError("seeded bootstrap key: body count mismatch")
+    bsk = np.zeros(params.bsk_len, dtype=np.uint64)
+    _check(_sigs().fhe_seeded_decompress_bootstrap_key(C.byref(params.c()), _seed16(seed), _ptr(bodies), _ptr(bsk)))
+    return bsk
+
+
+def split_keyswitch_key(params: Params, ksk) -> np.ndarray:
+    ksk = _u64(ksk)
+    bodies = np.zeros(ksk_bodies_len(params), dtype=np.uint64)
+    _check(_sigs().fhe_seeded_split_keyswitch_key(C.byref(params.c()), _ptr(ksk), _ptr(bodies)))
+    return bodies
+
+
+def split_bootstrap_key(params: Params, bsk) -> np.ndarray:
+    bsk = _u64(bsk)
+    bodies = np.zeros(bsk_bodies_len(params), dtype=np.uint64)
+    _check(_sigs().fhe_seeded_split_bootstrap_key(C.byref(params.c()), _ptr(bsk), _ptr(bodies)))
+    return bodies
+
+
+def write_seeded_keyswitch_key(params: Params, seed, bodies) -> bytes:
+    bodies, sd = _u64(bodies), _seed16(seed)
+    return _write(lambda out, cap, n: _sigs().fhe_wire_write_seeded_keyswitch_key(C.byref(params.c()), sd, _ptr(bodies), out, cap, n))
+
+
+def read_seeded_keyswitch_key(params: Params, data: bytes):
+    """-> (seed bytes, bodies)"""
+    bodies, sd, used = np.zeros(ksk_bodies_len(params), dtype=np.uint64), (C.c_uint8 * 16)(), C.c_size_t()
+    _check(_sigs().fhe_wire_read_seeded_keyswitch_key(C.byref(params.c()), _in(data), len(data), sd, _ptr(bodies), C.byref(used)))
+    return bytes(sd), bodies
+
+
+def write_seeded_bootstrap_key(params: Params, seed, bodies) -> bytes:
+    bodies, sd = _u64(bodies), _seed16(seed)
+    return _write(lambda out, cap, n: _sigs().fhe_wire_write_seeded_bootstrap_key(C.byref(params.c()), sd, _ptr(bodies), out, cap, n))
+
+
+def read_seeded_bootstrap_key(params: Params, data: bytes):
+    """-> (seed bytes, bodies); the multi-bit container when the parameter set has a grouping factor"""
+    bodies, sd, used = np.zeros(bsk_bodies_len(params), dtype=np.uint64), (C.c_uint8 * 16)(), C.c_size_t()
+    _check(_sigs().fhe_wire_read_seeded_bootstrap_key(C.byref(params.c()), _in(data), len(data), sd, _ptr(bodies), C.byref(used)))
+    return bytes(sd), bodies
+
+
+def write_multi_bit_bootstrap_key(params: Params, bsk) -> bytes:
+    bsk = _u64(bsk)
+    if bsk.size != params.bsk_len:
+        raise FheError("key size mismatch")
+    return _write(lambda out, cap, n: _sigs().fhe_wire_write_multi_bit_bootstrap_key(C.byref(params.c()), _ptr(bsk), out, cap, n))
+
+
+def read_multi_bit_bootstrap_key(params: Params, data: bytes) -> np.ndarray:
+    bsk, used = np.zeros(params.bsk_len, dtype=np.uint64), C.c_size_t()
+    _check(_sigs().fhe_wire_read_multi_bit_bootstrap_key(C.byref(params.c()), _in(data), len(data), _ptr(bsk), C.byref(used)))
+    return bsk

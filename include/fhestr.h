@@ -342,6 +342,41 @@ int fhe_wire_read_shortint_ciphertext(const uint8_t *in, size_t in_len, int safe
                                       uint64_t *ct, size_t ct_cap, size_t *lwe_size, fhe_shortint_meta *meta,
                                       size_t *consumed);
 
+/* ---- seeded ("compressed") server keys -------------------------------------------------------
+ * What a tfhe-rs client sends: shortint CompressedServerKey = SeededLweKeyswitchKey + SeededLweBootstrapKey
+ * (or SeededLweMultiBitBootstrapKey), shortint/server_key/compressed.rs.  A seeded key holds the bodies only
+ * (keyswitch key: k*N*ks_level words; bootstrap key: n_ggsw*pbs_level*(k+1) polynomials of N words) and a
+ * 128-bit compression seed; the masks are the seed's AES-128-CTR stream (concrete-csprng) in storage order
+ * (seeded_lwe_keyswitch_key_decompression.rs, seeded_lwe_bootstrap_key_decompression.rs,
+ * seeded_lwe_multi_bit_bootstrap_key_decompression.rs; details in csrc/seeded_keys.cpp).
+ * fhe_seeded_decompress_* rebuild the standard-domain keys fhe_engine_load_keys takes; fhe_seeded_split_* are
+ * the inverse (bodies of a standard key); fhe_seeded_mask_words exposes the mask stream (tests, and clients that
+ * want to ENCRYPT seeded keys).  The AES block function carries the FIPS-197 vector the reference tests with;
+ * stream position, integer packing and draw order follow the reference's sources: parity with a real client
+ * is unpinned (no seeded fixture in the reference). */
+int fhe_aes128_encrypt_block(const uint8_t key[16], const uint8_t in[16], uint8_t out[16]);
+int fhe_seeded_mask_words(const uint8_t seed[16], uint64_t *out, size_t count);
+int fhe_seeded_decompress_keyswitch_key(const fhe_params_t *p, const uint8_t seed[16], const uint64_t *bodies, uint64_t *ksk);
+int fhe_seeded_decompress_bootstrap_key(const fhe_params_t *p, const uint8_t seed[16], const uint64_t *bodies,
+                                        uint64_t *bsk_std);
+int fhe_seeded_split_keyswitch_key(const fhe_params_t *p, const uint64_t *ksk, uint64_t *bodies);
+int fhe_seeded_split_bootstrap_key(const fhe_params_t *p, const uint64_t *bsk_std, uint64_t *bodies);
+/* bincode forms (entities/seeded_lwe_keyswitch_key.rs:11-21, seeded_ggsw_ciphertext_list.rs:12-23,
+ * seeded_lwe_multi_bit_bootstrap_key.rs:16-25, lwe_multi_bit_bootstrap_key.rs:11-20); the bootstrap-key
+ * functions read / write the multi-bit container when the parameter set has a grouping factor */
+int fhe_wire_write_seeded_keyswitch_key(const fhe_params_t *p, const uint8_t seed[16], const uint64_t *bodies, uint8_t *out,
+                                        size_t out_cap, size_t *written);
+int fhe_wire_read_seeded_keyswitch_key(const fhe_params_t *p, const uint8_t *in, size_t in_len, uint8_t seed[16],
+                                       uint64_t *bodies, size_t *consumed);
+int fhe_wire_write_seeded_bootstrap_key(const fhe_params_t *p, const uint8_t seed[16], const uint64_t *bodies, uint8_t *out,
+                                        size_t out_cap, size_t *written);
+int fhe_wire_read_seeded_bootstrap_key(const fhe_params_t *p, const uint8_t *in, size_t in_len, uint8_t seed[16],
+                                       uint64_t *bodies, size_t *consumed);
+int fhe_wire_write_multi_bit_bootstrap_key(const fhe_params_t *p, const uint64_t *bsk_std, uint8_t *out, size_t out_cap,
+                                           size_t *written);
+int fhe_wire_read_multi_bit_bootstrap_key(const fhe_params_t *p, const uint8_t *in, size_t in_len, uint64_t *bsk_std,
+                                          size_t *consumed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,182 @@
+"""Seeded ("compressed") server keys -- what a tfhe-rs client sends (shortint/server_key/compressed.rs) -- and the
+multi-bit bootstrap key container (csrc/seeded_keys.cpp, include/fhestr.h "seeded server keys").
+
+Pinned by the reference: the AES-128 block function (the FIPS-197 vector its own test uses,
+concrete-csprng/src/generators/implem/soft/block_cipher.rs:89-91).  Checked against an independent restatement
+written here from the reference's sources: where the mask stream starts (table index SECOND, aes_ctr/index.rs:27-31),
+how integers are packed (uniform.rs:15-24) and the order masks are drawn in (seeded_*_decompression.rs), end to
+end on a re-masked oracle key that must still bootstrap correctly.  The reference holds no seeded-key fixture:
+byte-level parity with a real tfhe-rs client is unpinned."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+TOY = O.TOY_K1          # n = 16, k = 1, N = 256, two levels
+
+
+def _fp(p, grouping=0):
+    import fhestr
+    return fhestr.Params(p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, p.ks_base_log, p.ks_level, p.msg_mod, p.carry_mod,
+                         p.lwe_std, p.glwe_std, p.name, grouping)
+
+
+# ---- independent AES-128 / counter-mode restatement (S-box from its algebraic definition) ---------------------------
+def _gf_mul(a, b):
+    r = 0
+    for _ in range(8):
+        if b & 1:
+            r ^= a
+        a = ((a << 1) ^ 0x11B) if a & 0x80 else a << 1
+        b >>= 1
+    return r
+
+
+def _sbox():
+    inv = [0] * 256
+    for a in range(1, 256):
+        inv[a] = next(b for b in range(1, 256) if _gf_mul(a, b) == 1)
+    rot = lambda x, s: ((x << s) | (x >> (8 - s))) & 0xFF
+    return [inv[a] ^ rot(inv[a], 1) ^ rot(inv[a], 2) ^ rot(inv[a], 3) ^ rot(inv[a], 4) ^ 0x63 for a in range(256)]
+
+
+SBOX = _sbox()
+
+
+def _aes128(key: bytes, block: bytes) -> bytes:
+    w = [list(key[4 * i: 4 * i + 4]) for i in range(4)]
+    rcon = 1
+    for i in range(4, 44):
+        t = list(w[i - 1])
+        if i % 4 == 0:
+            t = [SBOX[b] for b in t[1:] + t[:1]]
+            t[0] ^= rcon
+            rcon = _gf_mul(rcon, 2)
+        w.append([a ^ b for a, b in zip(w[i - 4], t)])
+    rk = [sum(w[4 * r: 4 * r + 4], []) for r in range(11)]
+    s = [a ^ b for a, b in zip(block, rk[0])]
+    for r in range(1, 11):
+        s = [SBOX[s[4 * ((c + row) % 4) + row]] for c in range(4) for row in range(4)]
+        if r < 10:
+            m = []
+            for c in range(4):
+                a = s[4 * c: 4 * c + 4]
+                m += [_gf_mul(a[0], 2) ^ _gf_mul(a[1], 3) ^ a[2] ^ a[3], a[0] ^ _gf_mul(a[1], 2) ^ _gf_mul(a[2], 3) ^ a[3],
+                      a[0] ^ a[1] ^ _gf_mul(a[2], 2) ^ _gf_mul(a[3], 3), _gf_mul(a[0], 3) ^ a[1] ^ a[2] ^ _gf_mul(a[3], 2)]
+            s = m
+        s = [a ^ b for a, b in zip(s, rk[r])]
+    return bytes(s)
+
+
+def _mask_words(seed: int, count: int) -> np.ndarray:
+    """MaskRandomGenerator::new(Seed(seed)): AES_seed(counter as LE u128) blocks, from byte 1 on, 8 bytes LE per u64."""
+    key = seed.to_bytes(16, "little")
+    need = 1 + 8 * count
+    stream = b"".join(_aes128(key, a.to_bytes(16, "little")) for a in range((need + 15) // 16))
+    return np.frombuffer(stream[1: 1 + 8 * count], dtype="<u8").copy()
+
+
+def test_aes_block_is_the_fips_197_vector_of_the_reference_test():
+    from fhestr import wire
+    key = bytes.fromhex("000102030405060708090a0b0c0d0e0f")
+    pt = bytes.fromhex("00112233445566778899aabbccddeeff")
+    want = bytes.fromhex("69c4e0d86a7b0430d8cdb78070b4c55a")
+    assert wire.aes128_encrypt_block(key, pt) == want == _aes128(key, pt)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 0x0123456789ABCDEF0FEDCBA987654321, (1 << 128) - 1])
+def test_mask_stream_matches_the_independent_restatement(seed):
+    from fhestr import wire
+    assert np.array_equal(wire.seeded_mask_words(seed, 67), _mask_words(seed, 67))      # crosses block boundaries unaligned
+
+
+def _remasked(p, ck, sk, seed_ksk, seed_bsk):
+    """Bodies of a seeded key pair that encrypts what the oracle's keys encrypt, under the seeds' masks: for every
+    ciphertext, body' = body - <old mask, s> + <new mask, s>; new masks drawn in storage order."""
+    n, N, k = p.n, p.N, p.k
+    rows = p.big_dim * p.ks_level
+    old = sk.ksk.reshape(rows, n + 1)
+    new_mask = _mask_words(seed_ksk, rows * n).reshape(rows, n)
+    s = ck.small_sk
+    ksk_bodies = old[:, n] - (old[:, :n] * s).sum(axis=1, dtype=np.uint64) + (new_mask * s).sum(axis=1, dtype=np.uint64)
+    grows = p.n * p.pbs_level * (k + 1)
+    oldg = sk.bsk.reshape(grows, k + 1, N)
+    newg = _mask_words(seed_bsk, grows * k * N).reshape(grows, k, N)
+    S = ck.glwe_sk.reshape(k, N)
+    bsk_bodies = np.zeros((grows, N), dtype=np.uint64)
+    for r in range(grows):
+        b = oldg[r, k].copy()
+        for j in range(k):
+            b = b - O.negacyclic_schoolbook(oldg[r, j], S[j]) + O.negacyclic_schoolbook(newg[r, j], S[j])
+        bsk_bodies[r] = b
+    return ksk_bodies, bsk_bodies.reshape(-1), new_mask, newg
+
+
+def test_decompressed_seeded_keys_bootstrap_correctly():
+    from fhestr import wire
+    p, fp = TOY, _fp(TOY)
+    ck = O.ClientKey(p, 0x5EED)
+    sk = O.ServerKey(ck)
+    seed_ksk, seed_bsk = 0x1111222233334444AAAABBBBCCCCDDDD, 7
+    kb, bb, km, gm = _remasked(p, ck, sk, seed_ksk, seed_bsk)
+    ksk = wire.decompress_keyswitch_key(fp, seed_ksk, kb)
+    bsk = wire.decompress_bootstrap_key(fp, seed_bsk, bb)
+    # masks where the reference draws them, bodies where the seeded containers hold them
+    assert np.array_equal(ksk.reshape(-1, p.n + 1)[:, :p.n], km) and np.array_equal(ksk.reshape(-1, p.n + 1)[:, p.n], kb)
+    g = bsk.reshape(-1, p.k + 1, p.N)
+    assert np.array_equal(g[:, :p.k], gm) and np.array_equal(g[:, p.k].reshape(-1), bb)
+    assert not np.array_equal(ksk, sk.ksk)
+    # inverse
+    assert np.array_equal(wire.split_keyswitch_key(fp, ksk), kb) and np.array_equal(wire.split_bootstrap_key(fp, bsk), bb)
+    # the rebuilt keys are valid keys: every message through a table
+    sk.ksk, sk.bsk = ksk, bsk
+    sk.fbsk = np.zeros(bsk.size, dtype=np.float64)
+    O.lib().orc_bsk_to_fourier(C.byref(p.c()), sk.bsk, sk.fbsk)
+    M = p.msg_mod * p.carry_mod
+    f = lambda x: (3 * x + 1) % M
+    lut, _ = sk.generate_lookup_table(f)
+    out = sk.apply_lookup_table_batch(ck.encrypt_many(range(M)), lut)
+    assert np.array_equal(ck.decrypt_many(out), [f(m) for m in range(M)])
+
+
+def test_seeded_key_wire_layouts_and_round_trips():
+    from fhestr import wire, FheError
+    fp = _fp(O.TOY_K2)                                   # n = 12, k = 2, N = 128, one level; ks (3, 5)
+    rng = np.random.default_rng(3)
+    seed = 0x00112233445566778899AABBCCDDEEFF
+    kb = rng.integers(0, 1 << 63, size=wire.ksk_bodies_len(fp), dtype=np.uint64)
+    blob = wire.write_seeded_keyswitch_key(fp, seed, kb)
+    # SeededLweKeyswitchKey { data, decomp_base_log, decomp_level_count, output_lwe_size, compression_seed, ciphertext_modulus }
+    want = struct.pack("<Q", kb.size) + kb.tobytes() + struct.pack("<QQQ", fp.ks_base_log, fp.ks_level, fp.n + 1) + \
+        seed.to_bytes(16, "little") + struct.pack("<QQQ", 0, 0, 64)
+    assert blob == want
+    s2, kb2 = wire.read_seeded_keyswitch_key(fp, blob)
+    assert s2 == seed.to_bytes(16, "little") and np.array_equal(kb2, kb)
+    bb = rng.integers(0, 1 << 63, size=wire.bsk_bodies_len(fp), dtype=np.uint64)
+    blob = wire.write_seeded_bootstrap_key(fp, seed, bb)
+    want = struct.pack("<Q", bb.size) + bb.tobytes() + struct.pack("<QQQQ", fp.k + 1, fp.N, fp.pbs_base_log, fp.pbs_level) + \
+        seed.to_bytes(16, "little") + struct.pack("<QQQ", 0, 0, 64)
+    assert blob == want
+    s2, bb2 = wire.read_seeded_bootstrap_key(fp, blob)
+    assert s2 == seed.to_bytes(16, "little") and np.array_equal(bb2, bb)
+    with pytest.raises(FheError):
+        wire.read_seeded_bootstrap_key(fp, blob[:-9])                    # truncated
+    with pytest.raises(FheError):
+        wire.read_seeded_keyswitch_key(_fp(O.TOY_K1), wire.write_seeded_keyswitch_key(fp, seed, kb))   # other parameter set
+    # multi-bit: grouping factor after the GGSW list (seeded_lwe_multi_bit_bootstrap_key.rs:16-25, lwe_multi_bit_bootstrap_key.rs:11-20)
+    mp = _fp(O.TOY_K2, grouping=2)
+    mb = rng.integers(0, 1 << 63, size=wire.bsk_bodies_len(mp), dtype=np.uint64)
+    assert mb.size == 2 * bb.size                                        # n/2 groups of 4 GGSWs
+    blob = wire.write_seeded_bootstrap_key(mp, seed, mb)
+    assert blob[-8:] == struct.pack("<Q", 2)
+    assert np.array_equal(wire.read_seeded_bootstrap_key(mp, blob)[1], mb)
+    full = rng.integers(0, 1 << 63, size=mp.bsk_len, dtype=np.uint64)
+    blob = wire.write_multi_bit_bootstrap_key(mp, full)
+    assert blob == struct.pack("<Q", full.size) + full.tobytes() + struct.pack("<QQQQ", mp.k + 1, mp.N, mp.pbs_base_log, mp.pbs_level) + \
+        struct.pack("<QQQ", 0, 0, 64) + struct.pack("<Q", 2)
+    assert np.array_equal(wire.read_multi_bit_bootstrap_key(mp, blob), full)
+    with pytest.raises(FheError):
+        wire.read_multi_bit_bootstrap_key(_fp(O.TOY_K2, grouping=3), blob)
