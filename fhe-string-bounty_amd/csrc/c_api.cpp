@@ -85,6 +85,14 @@ int fhe_engine_set_variant(fhe_engine* eng, int log2_points) {
     API_END
 }
 
+int fhe_engine_load_seeded_keys(fhe_engine* eng, const uint8_t ksk_seed[16], const uint64_t* ksk_bodies, const uint8_t bsk_seed[16],
+                                const uint64_t* bsk_bodies, uint64_t* bsk_std_out, uint64_t* ksk_out) {
+    API_BEGIN
+    CHECK_PTR(eng); CHECK_PTR(ksk_seed); CHECK_PTR(ksk_bodies); CHECK_PTR(bsk_seed); CHECK_PTR(bsk_bodies);
+    return eng->impl->load_seeded_keys(ksk_seed, ksk_bodies, bsk_seed, bsk_bodies, bsk_std_out, ksk_out);
+    API_END
+}
+
 int fhe_engine_set_multibit_combine_max(fhe_engine* eng, uint32_t max_batch) {
     API_BEGIN
     CHECK_PTR(eng);

@@ -27,6 +27,9 @@ inline uint64_t multi_bit_key_bit(const uint64_t* group_bits, uint32_t g, uint32
     return prod;
 }
 
+void aes128_round_keys(const uint8_t key[16], uint8_t rk[11][16]);   // seeded_keys.cpp
+const uint8_t* aes_sbox();
+
 extern thread_local std::string g_last_error;
 int fail(const std::string& msg);
 
@@ -72,6 +75,8 @@ struct Engine {
     int use();
     int set_variant(int logR);
     int load_keys(const uint64_t* bsk_std, const uint64_t* ksk);
+    int load_seeded_keys(const uint8_t ksk_seed[16], const uint64_t* ksk_bodies, const uint8_t bsk_seed[16], const uint64_t* bsk_bodies,
+                         uint64_t* bsk_std_out, uint64_t* ksk_out);
     int generate_keys(const uint64_t* glwe_sk, const uint64_t* small_sk, const uint8_t seed[32],
                       uint64_t* bsk_std_out, uint64_t* ksk_out);
     int install_keys(uint64_t* d_ksk_std, uint64_t* d_bsk_std);

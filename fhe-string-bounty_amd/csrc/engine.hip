@@ -21,6 +21,7 @@
 #include "pbs_large_kernels.hip.h"
 #include "pbs_multibit_kernels.hip.h"
 #include "pbs_seq_kernels.hip.h"
+#include "seeded_kernels.hip.h"
 
 namespace fhe {
 
@@ -347,6 +348,47 @@ int Engine::load_keys(const uint64_t* bsk_std, const uint64_t* ksk) {
         (void)hipFree(d_ksk_std); (void)hipFree(d_bsk_std);
         return fail(std::string("key upload: ") + hipGetErrorString(e));
     }
+    return install_keys(d_ksk_std, d_bsk_std);
+}
+
+// A tfhe-rs client's CompressedServerKey (shortint/server_key/compressed.rs): upload the bodies, expand the masks from
+// the two compression seeds on the device (seeded_kernels.hip.h), then install as usual.
+int Engine::load_seeded_keys(const uint8_t ksk_seed[16], const uint64_t* ksk_bodies, const uint8_t bsk_seed[16],
+                             const uint64_t* bsk_bodies, uint64_t* bsk_std_out, uint64_t* ksk_out) {
+    if (use()) return 1;
+    const uint64_t ksk_rows = (uint64_t)p.k * p.N * p.ks_level, bsk_rows = (uint64_t)n_ggsw(p) * p.pbs_level * (p.k + 1);
+    const size_t ksk_len = ksk_rows * (p.n + 1), bsk_len = bsk_rows * (p.k + 1) * p.N;
+    const size_t bsk_body_words = bsk_rows * p.N;
+    uint64_t *d_ksk_std = nullptr, *d_bsk_std = nullptr, *d_bodies = nullptr;
+    uint8_t* d_sbox = nullptr;
+    auto cleanup = [&] { (void)hipFree(d_ksk_std); (void)hipFree(d_bsk_std); (void)hipFree(d_bodies); (void)hipFree(d_sbox); };
+    hipError_t e = hipMalloc((void**)&d_ksk_std, ksk_len * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_bsk_std, bsk_len * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_bodies, (bsk_body_words + ksk_rows) * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_sbox, 256);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_sbox, aes_sbox(), 256, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_bodies, bsk_bodies, bsk_body_words * 8, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_bodies + bsk_body_words, ksk_bodies, ksk_rows * 8, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) { cleanup(); return fail(std::string("load_seeded_keys: ") + hipGetErrorString(e)); }
+    SeededExpandArgs ka{}, ba{};
+    aes128_round_keys(ksk_seed, ka.round_keys);
+    ka.out = d_ksk_std; ka.rows = ksk_rows; ka.mask_per_row = p.n; ka.row_words = p.n + 1;
+    aes128_round_keys(bsk_seed, ba.round_keys);
+    ba.out = d_bsk_std; ba.rows = bsk_rows; ba.mask_per_row = p.k * p.N; ba.row_words = (p.k + 1) * p.N;
+    const unsigned grid = (unsigned)cu_count * 8;
+    hipLaunchKernelGGL(seeded_expand_kernel, dim3(grid), dim3(256), 0, stream, ka, d_sbox);
+    hipLaunchKernelGGL(seeded_expand_kernel, dim3(grid), dim3(256), 0, stream, ba, d_sbox);
+    hipLaunchKernelGGL(seeded_scatter_bodies_kernel, dim3(grid), dim3(256), 0, stream, d_bodies + bsk_body_words, d_ksk_std, ksk_rows,
+                       p.n, p.n + 1);
+    hipLaunchKernelGGL(seeded_scatter_bodies_kernel, dim3(grid), dim3(256), 0, stream, d_bodies, d_bsk_std, bsk_rows, p.k * p.N,
+                       (p.k + 1) * p.N);
+    e = hipGetLastError();
+    if (e == hipSuccess && ksk_out) e = hipMemcpyAsync(ksk_out, d_ksk_std, ksk_len * 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && bsk_std_out) e = hipMemcpyAsync(bsk_std_out, d_bsk_std, bsk_len * 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_bodies); d_bodies = nullptr;
+    (void)hipFree(d_sbox); d_sbox = nullptr;
+    if (e != hipSuccess) { cleanup(); return fail(std::string("load_seeded_keys: ") + hipGetErrorString(e)); }
     return install_keys(d_ksk_std, d_bsk_std);
 }
 

@@ -200,6 +200,15 @@ bool read_ggsw_list_meta(Reader& r, const fhe_params_t& p, std::string& why) {
 
 }  // namespace
 
+namespace fhe {
+// for the device-side expansion (seeded_kernels.hip.h)
+void aes128_round_keys(const uint8_t key[16], uint8_t rk[11][16]) {
+    const Aes128 a(key);
+    std::memcpy(rk, a.rk, sizeof(a.rk));
+}
+const uint8_t* aes_sbox() { return kSbox; }
+}  // namespace fhe
+
 extern "C" {
 
 int fhe_aes128_encrypt_block(const uint8_t key[16], const uint8_t in[16], uint8_t out[16]) {

@@ -125,7 +125,7 @@ _lib = None
 EXPORTS = [
     "fhe_last_error", "fhe_kernel_revision", "fhe_engine_create", "fhe_engine_destroy", "fhe_engine_params",
     "fhe_engine_load_keys", "fhe_engine_generate_keys", "fhe_engine_stream", "fhe_engine_synchronize", "fhe_engine_set_variant",
-    "fhe_engine_set_multibit_combine_max",
+    "fhe_engine_set_multibit_combine_max", "fhe_engine_load_seeded_keys",
     "fhe_lut_generate", "fhe_lut_upload", "fhe_lut_download", "fhe_lut_count",
     "fhe_keyswitch_batch", "fhe_pbs_batch", "fhe_ks_pbs_batch", "fhe_ks_pbs_batch_dev", "fhe_pbs_ks_batch",
     "fhe_lwe_lincomb_batch", "fhe_last_kernel_ms", "fhe_kernel_times",
@@ -195,6 +195,7 @@ def lib() -> C.CDLL:
     sig("fhe_engine_synchronize", vp)
     sig("fhe_engine_set_variant", vp, i32)
     sig("fhe_engine_set_multibit_combine_max", vp, u32)
+    sig("fhe_engine_load_seeded_keys", vp, vp, vp, vp, vp, vp, vp)
     sig("fhe_lut_generate", vp, vp, C.POINTER(u32), C.POINTER(C.c_uint64))
     sig("fhe_lut_upload", vp, vp, C.POINTER(u32))
     sig("fhe_lut_download", vp, u32, vp)
@@ -325,6 +326,21 @@ class Engine:
         _check(lib().fhe_engine_create(C.byref(params.c()), device, C.byref(self._h)))
         if log2_points:
             _check(lib().fhe_engine_set_variant(self._h, log2_points))
+
+    def load_seeded_keys(self, ksk_seed, ksk_bodies, bsk_seed, bsk_bodies, export: bool = False):
+        """A tfhe-rs CompressedServerKey (shortint/server_key/compressed.rs): bodies + two 128-bit compression seeds
+        (16 bytes, or ints = Seed(u128)); the masks are expanded on the GPU.  export=True returns (bsk_std, ksk)."""
+        p = self.params
+        kb, bb = _u64(ksk_bodies), _u64(bsk_bodies)
+        if kb.size != p.k * p.N * p.ks_level or bb.size != p.n_ggsw * p.pbs_level * (p.k + 1) * p.N:
+            raise FheError("seeded key: body count does not match the parameter set")
+        seeds = [(C.c_uint8 * 16).from_buffer_copy(s.to_bytes(16, "little") if isinstance(s, int) else bytes(s))
+                 for s in (ksk_seed, bsk_seed)]
+        bsk = np.zeros(p.bsk_len, dtype=np.uint64) if export else None
+        ksk = np.zeros(p.ksk_len, dtype=np.uint64) if export else None
+        _check(lib().fhe_engine_load_seeded_keys(self._h, seeds[0], _ptr(kb), seeds[1], _ptr(bb),
+                                                 _ptr(bsk) if export else None, _ptr(ksk) if export else None))
+        return (bsk, ksk) if export else None
 
     def set_multibit_combine_max(self, max_batch: int):
         """Multi-bit PBS: batches up to max_batch prepare their GGSWs on the whole GPU first (0 = always fused)."""

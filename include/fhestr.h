@@ -354,6 +354,12 @@ int fhe_wire_read_shortint_ciphertext(const uint8_t *in, size_t in_len, int safe
  * want to ENCRYPT seeded keys).  The AES block function carries the FIPS-197 vector the reference tests with;
  * stream position, integer packing and draw order follow the reference's sources: parity with a real client
  * is unpinned (no seeded fixture in the reference). */
+/* The device-side route: upload the bodies only and expand both mask streams on the GPU (csrc/seeded_kernels.hip.h),
+ * then install like fhe_engine_load_keys.  bsk_std_out / ksk_out (may be NULL) receive the standard-domain keys --
+ * bit-identical to fhe_seeded_decompress_*. */
+int fhe_engine_load_seeded_keys(fhe_engine *eng, const uint8_t ksk_seed[16], const uint64_t *ksk_bodies,
+                                const uint8_t bsk_seed[16], const uint64_t *bsk_bodies, uint64_t *bsk_std_out,
+                                uint64_t *ksk_out);
 int fhe_aes128_encrypt_block(const uint8_t key[16], const uint8_t in[16], uint8_t out[16]);
 int fhe_seeded_mask_words(const uint8_t seed[16], uint64_t *out, size_t count);
 int fhe_seeded_decompress_keyswitch_key(const fhe_params_t *p, const uint8_t seed[16], const uint64_t *bodies, uint64_t *ksk);

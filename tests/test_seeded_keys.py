@@ -180,3 +180,41 @@ def test_seeded_key_wire_layouts_and_round_trips():
     assert np.array_equal(wire.read_multi_bit_bootstrap_key(mp, blob), full)
     with pytest.raises(FheError):
         wire.read_multi_bit_bootstrap_key(_fp(O.TOY_K2, grouping=3), blob)
+
+
+@pytest.mark.gpu
+def test_gpu_expands_seeded_keys_like_the_host_and_bootstraps():
+    """fhe_engine_load_seeded_keys: masks from the GPU's AES counter-mode kernel == host decompression, bit for bit
+    (toy and PARAM_MESSAGE_2_CARRY_2 sizes, one multi-bit shape), and the re-masked oracle key bootstraps on the GPU."""
+    import fhestr
+    from fhestr import wire
+    p, fp = TOY, _fp(TOY)
+    ck = O.ClientKey(p, 0x5EED)
+    sk = O.ServerKey(ck, fourier=False)
+    seed_ksk, seed_bsk = 0xFEDCBA98765432100123456789ABCDEF, 42
+    kb, bb, _, _ = _remasked(p, ck, sk, seed_ksk, seed_bsk)
+    eng = fhestr.Engine(fp, 0)
+    try:
+        bsk, ksk = eng.load_seeded_keys(seed_ksk, kb, seed_bsk, bb, export=True)
+        assert np.array_equal(ksk, wire.decompress_keyswitch_key(fp, seed_ksk, kb))
+        assert np.array_equal(bsk, wire.decompress_bootstrap_key(fp, seed_bsk, bb))
+        M = p.msg_mod * p.carry_mod
+        f = lambda x: (5 * x + 2) % M
+        lut, _ = sk.generate_lookup_table(f)
+        lut_id = eng.upload_lut(lut)
+        msgs = np.arange(2 * M) % M
+        got = eng.apply_lookup_table(ck.encrypt_many(msgs, O.Rng(9, 9)), np.full(len(msgs), lut_id, dtype=np.uint32))
+        assert np.array_equal(ck.decrypt_many(got), [f(int(m)) for m in msgs])
+    finally:
+        eng.close()
+    rng = np.random.default_rng(8)
+    for P in (fhestr.PARAM_MESSAGE_2_CARRY_2_KS_PBS, _fp(O.TOY_K2, grouping=3)):
+        eng = fhestr.Engine(P, 0)
+        try:
+            kb = rng.integers(0, 1 << 63, size=wire.ksk_bodies_len(P), dtype=np.uint64)
+            bb = rng.integers(0, 1 << 63, size=wire.bsk_bodies_len(P), dtype=np.uint64)
+            bsk, ksk = eng.load_seeded_keys(3, kb, (1 << 127) + 5, bb, export=True)
+            assert np.array_equal(ksk, wire.decompress_keyswitch_key(P, 3, kb))
+            assert np.array_equal(bsk, wire.decompress_bootstrap_key(P, (1 << 127) + 5, bb))
+        finally:
+            eng.close()
