@@ -29,6 +29,7 @@
 // 89-91); the stream position, integer packing and draw order follow the files above and are checked here against an
 // independent restatement in the tests (tests/test_seeded_keys.py) -- the reference holds no seeded-key fixture, so
 // byte-level parity with a real tfhe-rs client IS UNPINNED.
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -350,6 +351,76 @@ int fhe_wire_read_multi_bit_bootstrap_key(const fhe_params_t* p, const uint8_t* 
         return fail("LweMultiBitBootstrapKey does not match the parameter set (" + why + ", grouping factor " + std::to_string(grouping) +
                     ", " + std::to_string(n) + " words)");
     if (consumed) *consumed = r.pos;
+    return 0;
+}
+
+// shortint CompressedServerKey (shortint/server_key/compressed.rs:44-55): { key_switching_key: SeededLweKeyswitchKey,
+// bootstrapping_key: enum { Classic(SeededLweBootstrapKey) = 0, MultiBit { seeded_bsk, deterministic_execution: bool } = 1 }
+// (:11-17), message_modulus, carry_modulus, max_degree, ciphertext_modulus, pbs_order (unit enum, u32) } -- the object a
+// client serializes for the server.
+int fhe_wire_write_compressed_server_key(const fhe_params_t* p, const uint8_t ksk_seed[16], const uint64_t* ksk_bodies,
+                                         const uint8_t bsk_seed[16], const uint64_t* bsk_bodies, uint64_t max_degree,
+                                         uint32_t pbs_order, uint8_t* out, size_t out_cap, size_t* written) {
+    if (!p || !ksk_seed || !ksk_bodies || !bsk_seed || !bsk_bodies) return fail("null pointer");
+    size_t pos = 0, n = 0;
+    bool overflow = false;
+    auto room = [&](size_t at) { return out && at < out_cap ? out_cap - at : 0; };
+    auto part = [&](int rc) { if (rc) overflow = true; pos += n; };
+    part(fhe_wire_write_seeded_keyswitch_key(p, ksk_seed, ksk_bodies, out ? out + std::min(pos, out_cap) : nullptr, room(pos), &n));
+    Writer w{out ? out + std::min(pos, out_cap) : nullptr, room(pos)};
+    const uint32_t tag = p->grouping_factor > 1 ? 1u : 0u;
+    for (int i = 0; i < 4; i++) { const uint8_t b = (uint8_t)(tag >> (8 * i)); w.bytes(&b, 1); }
+    overflow |= w.overflow;
+    pos += w.pos;
+    part(fhe_wire_write_seeded_bootstrap_key(p, bsk_seed, bsk_bodies, out ? out + std::min(pos, out_cap) : nullptr, room(pos), &n));
+    Writer t{out ? out + std::min(pos, out_cap) : nullptr, room(pos)};
+    if (tag == 1) { const uint8_t deterministic = 1; t.bytes(&deterministic, 1); }
+    t.u64(p->msg_mod);
+    t.u64(p->carry_mod);
+    t.u64(max_degree);
+    t.native_modulus_u64();
+    for (int i = 0; i < 4; i++) { const uint8_t b = (uint8_t)(pbs_order >> (8 * i)); t.bytes(&b, 1); }
+    overflow |= t.overflow;
+    pos += t.pos;
+    if (written) *written = pos;
+    if (out && overflow) return fail("output buffer too small: " + std::to_string(pos) + " bytes needed");
+    return 0;
+}
+
+int fhe_wire_read_compressed_server_key(const fhe_params_t* p, const uint8_t* in, size_t in_len, uint8_t ksk_seed[16],
+                                        uint64_t* ksk_bodies, uint8_t bsk_seed[16], uint64_t* bsk_bodies, uint64_t* max_degree,
+                                        uint32_t* pbs_order, size_t* consumed) {
+    if (!p || !in || !ksk_seed || !ksk_bodies || !bsk_seed || !bsk_bodies) return fail("null pointer");
+    size_t pos = 0, n = 0;
+    if (fhe_wire_read_seeded_keyswitch_key(p, in, in_len, ksk_seed, ksk_bodies, &n)) return 1;
+    pos += n;
+    Reader r{in + pos, in_len - pos};
+    uint8_t tb[4] = {0, 0, 0, 0};
+    r.raw(tb, 4);
+    if (!r.err.empty()) return fail("CompressedServerKey: " + r.err);
+    const uint32_t tag = (uint32_t)tb[0] | (uint32_t)tb[1] << 8 | (uint32_t)tb[2] << 16 | (uint32_t)tb[3] << 24;
+    if (tag > 1) return fail("CompressedServerKey: unknown bootstrapping key variant " + std::to_string(tag));
+    if ((tag == 1) != (p->grouping_factor > 1))
+        return fail(tag == 1 ? "CompressedServerKey holds a multi-bit bootstrapping key, the parameter set is classic"
+                             : "CompressedServerKey holds a classic bootstrapping key, the parameter set is multi-bit");
+    pos += 4;
+    if (fhe_wire_read_seeded_bootstrap_key(p, in + pos, in_len - pos, bsk_seed, bsk_bodies, &n)) return 1;
+    pos += n;
+    Reader t{in + pos, in_len - pos};
+    if (tag == 1) { uint8_t deterministic = 0; t.raw(&deterministic, 1); if (deterministic > 1 && t.err.empty()) t.err = "invalid bool"; }
+    const uint64_t msg = t.u64(), carry = t.u64(), deg = t.u64();
+    t.native_modulus_u64();
+    uint8_t ob[4] = {0, 0, 0, 0};
+    t.raw(ob, 4);
+    if (!t.err.empty()) return fail("CompressedServerKey: " + t.err);
+    const uint32_t order = (uint32_t)ob[0] | (uint32_t)ob[1] << 8 | (uint32_t)ob[2] << 16 | (uint32_t)ob[3] << 24;
+    if (msg != p->msg_mod || carry != p->carry_mod)
+        return fail("CompressedServerKey: message / carry modulus " + std::to_string(msg) + " / " + std::to_string(carry) +
+                    " do not match the parameter set");
+    if (order > 1) return fail("CompressedServerKey: unknown PBSOrder " + std::to_string(order));
+    if (max_degree) *max_degree = deg;
+    if (pbs_order) *pbs_order = order;
+    if (consumed) *consumed = pos + t.pos;
     return 0;
 }
 

@@ -49,6 +49,8 @@ def _sigs():
             ("fhe_wire_read_seeded_keyswitch_key", [PP, vp, sz, vp, vp, szp]),
             ("fhe_wire_write_seeded_bootstrap_key", [PP, vp, vp, vp, sz, szp]),
             ("fhe_wire_read_seeded_bootstrap_key", [PP, vp, sz, vp, vp, szp]),
+            ("fhe_wire_write_compressed_server_key", [PP, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, sz, szp]),
+            ("fhe_wire_read_compressed_server_key", [PP, vp, sz, vp, vp, vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), szp]),
             ("fhe_wire_write_multi_bit_bootstrap_key", [PP, vp, vp, sz, szp]),
             ("fhe_wire_read_multi_bit_bootstrap_key", [PP, vp, sz, vp, szp]),
             ("fhe_wire_write_shortint_ciphertext", [vp, sz, C.POINTER(_Meta), C.c_int, vp, sz, szp]),
@@ -227,3 +229,25 @@ def read_multi_bit_bootstrap_key(params: Params, data: bytes) -> np.ndarray:
     bsk, used = np.zeros(params.bsk_len, dtype=np.uint64), C.c_size_t()
     _check(_sigs().fhe_wire_read_multi_bit_bootstrap_key(C.byref(params.c()), _in(data), len(data), _ptr(bsk), C.byref(used)))
     return bsk
+
+
+def write_compressed_server_key(params: Params, ksk_seed, ksk_bodies, bsk_seed, bsk_bodies, max_degree: int | None = None,
+                                pbs_order: int = 0) -> bytes:
+    """shortint CompressedServerKey (shortint/server_key/compressed.rs:44-55)."""
+    kb, bb, ks, bs = _u64(ksk_bodies), _u64(bsk_bodies), _seed16(ksk_seed), _seed16(bsk_seed)
+    deg = params.msg_mod * params.carry_mod - 1 if max_degree is None else max_degree
+    return _write(lambda out, cap, n: _sigs().fhe_wire_write_compressed_server_key(
+        C.byref(params.c()), ks, _ptr(kb), bs, _ptr(bb), deg, pbs_order, out, cap, n))
+
+
+def read_compressed_server_key(params: Params, data: bytes) -> dict:
+    """-> {ksk_seed, ksk_bodies, bsk_seed, bsk_bodies, max_degree, pbs_order, consumed}: feed the first four to
+    Engine.load_seeded_keys."""
+    kb = np.zeros(ksk_bodies_len(params), dtype=np.uint64)
+    bb = np.zeros(bsk_bodies_len(params), dtype=np.uint64)
+    ks, bs = (C.c_uint8 * 16)(), (C.c_uint8 * 16)()
+    deg, order, used = C.c_uint64(), C.c_uint32(), C.c_size_t()
+    _check(_sigs().fhe_wire_read_compressed_server_key(C.byref(params.c()), _in(data), len(data), ks, _ptr(kb), bs, _ptr(bb),
+                                                       C.byref(deg), C.byref(order), C.byref(used)))
+    return {"ksk_seed": bytes(ks), "ksk_bodies": kb, "bsk_seed": bytes(bs), "bsk_bodies": bb, "max_degree": deg.value,
+            "pbs_order": order.value, "consumed": used.value}

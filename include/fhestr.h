@@ -378,6 +378,15 @@ int fhe_wire_write_seeded_bootstrap_key(const fhe_params_t *p, const uint8_t see
                                         size_t out_cap, size_t *written);
 int fhe_wire_read_seeded_bootstrap_key(const fhe_params_t *p, const uint8_t *in, size_t in_len, uint8_t seed[16],
                                        uint64_t *bodies, size_t *consumed);
+/* shortint CompressedServerKey, the object a client serializes for the server (shortint/server_key/compressed.rs:11-17,
+ * 44-55): seeded keyswitch key, Classic / MultiBit seeded bootstrap key (by the parameter set's grouping factor),
+ * message and carry modulus (checked against the parameter set), max_degree, ciphertext modulus, pbs_order. */
+int fhe_wire_write_compressed_server_key(const fhe_params_t *p, const uint8_t ksk_seed[16], const uint64_t *ksk_bodies,
+                                         const uint8_t bsk_seed[16], const uint64_t *bsk_bodies, uint64_t max_degree,
+                                         uint32_t pbs_order, uint8_t *out, size_t out_cap, size_t *written);
+int fhe_wire_read_compressed_server_key(const fhe_params_t *p, const uint8_t *in, size_t in_len, uint8_t ksk_seed[16],
+                                        uint64_t *ksk_bodies, uint8_t bsk_seed[16], uint64_t *bsk_bodies,
+                                        uint64_t *max_degree, uint32_t *pbs_order, size_t *consumed);
 int fhe_wire_write_multi_bit_bootstrap_key(const fhe_params_t *p, const uint64_t *bsk_std, uint8_t *out, size_t out_cap,
                                            size_t *written);
 int fhe_wire_read_multi_bit_bootstrap_key(const fhe_params_t *p, const uint8_t *in, size_t in_len, uint64_t *bsk_std,

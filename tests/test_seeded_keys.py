@@ -182,6 +182,30 @@ def test_seeded_key_wire_layouts_and_round_trips():
         wire.read_multi_bit_bootstrap_key(_fp(O.TOY_K2, grouping=3), blob)
 
 
+def test_compressed_server_key_container():
+    """shortint CompressedServerKey (shortint/server_key/compressed.rs:11-17,44-55): field order and enum tags."""
+    from fhestr import wire, FheError
+    rng = np.random.default_rng(5)
+    for grouping in (0, 2):
+        fp = _fp(O.TOY_K2, grouping=grouping)
+        kb = rng.integers(0, 1 << 63, size=wire.ksk_bodies_len(fp), dtype=np.uint64)
+        bb = rng.integers(0, 1 << 63, size=wire.bsk_bodies_len(fp), dtype=np.uint64)
+        blob = wire.write_compressed_server_key(fp, 11, kb, 22, bb, max_degree=3, pbs_order=0)
+        ksk_part = wire.write_seeded_keyswitch_key(fp, 11, kb)
+        bsk_part = wire.write_seeded_bootstrap_key(fp, 22, bb)
+        tail = (b"\x01" if grouping else b"") + struct.pack("<QQQ", fp.msg_mod, fp.carry_mod, 3) + struct.pack("<QQQ", 0, 0, 64) + \
+            struct.pack("<I", 0)
+        assert blob == ksk_part + struct.pack("<I", 1 if grouping else 0) + bsk_part + tail
+        got = wire.read_compressed_server_key(fp, blob + b"trailing")
+        assert got["consumed"] == len(blob) and got["max_degree"] == 3 and got["pbs_order"] == 0
+        assert got["ksk_seed"] == (11).to_bytes(16, "little") and got["bsk_seed"] == (22).to_bytes(16, "little")
+        assert np.array_equal(got["ksk_bodies"], kb) and np.array_equal(got["bsk_bodies"], bb)
+        with pytest.raises(FheError):
+            wire.read_compressed_server_key(_fp(O.TOY_K2, grouping=0 if grouping else 2), blob)      # Classic vs MultiBit
+        with pytest.raises(FheError):
+            wire.read_compressed_server_key(fp, blob[:-1])
+
+
 @pytest.mark.gpu
 def test_gpu_expands_seeded_keys_like_the_host_and_bootstraps():
     """fhe_engine_load_seeded_keys: masks from the GPU's AES counter-mode kernel == host decompression, bit for bit
