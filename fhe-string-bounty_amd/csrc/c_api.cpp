@@ -93,6 +93,16 @@ int fhe_engine_load_seeded_keys(fhe_engine* eng, const uint8_t ksk_seed[16], con
     API_END
 }
 
+int fhe_engine_expand_seeded_lwe(fhe_engine* eng, const uint8_t* seeds, const uint64_t* bodies, uint32_t count, uint64_t* d_out,
+                                 uint64_t* host_out) {
+    API_BEGIN
+    CHECK_PTR(eng);
+    if (count) { CHECK_PTR(seeds); CHECK_PTR(bodies); }
+    if (!d_out && !host_out) return fhe::fail("expand_seeded_lwe: no destination");
+    return eng->impl->expand_seeded_lwe(seeds, bodies, count, d_out, host_out);
+    API_END
+}
+
 int fhe_engine_set_multibit_combine_max(fhe_engine* eng, uint32_t max_batch) {
     API_BEGIN
     CHECK_PTR(eng);

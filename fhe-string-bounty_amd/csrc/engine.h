@@ -77,6 +77,7 @@ struct Engine {
     int load_keys(const uint64_t* bsk_std, const uint64_t* ksk);
     int load_seeded_keys(const uint8_t ksk_seed[16], const uint64_t* ksk_bodies, const uint8_t bsk_seed[16], const uint64_t* bsk_bodies,
                          uint64_t* bsk_std_out, uint64_t* ksk_out);
+    int expand_seeded_lwe(const uint8_t* seeds, const uint64_t* bodies, uint32_t count, uint64_t* d_out, uint64_t* host_out);
     int generate_keys(const uint64_t* glwe_sk, const uint64_t* small_sk, const uint8_t seed[32],
                       uint64_t* bsk_std_out, uint64_t* ksk_out);
     int install_keys(uint64_t* d_ksk_std, uint64_t* d_bsk_std);

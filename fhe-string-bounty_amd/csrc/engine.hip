@@ -392,6 +392,33 @@ int Engine::load_seeded_keys(const uint8_t ksk_seed[16], const uint64_t* ksk_bod
     return install_keys(d_ksk_std, d_bsk_std);
 }
 
+// Compressed big-key ciphertexts -> full ciphertexts in HBM (d_out, count x (kN+1) words) and/or host_out.
+int Engine::expand_seeded_lwe(const uint8_t* seeds, const uint64_t* bodies, uint32_t count, uint64_t* d_out, uint64_t* host_out) {
+    if (use()) return 1;
+    if (count == 0) return 0;
+    const uint32_t dim = p.k * p.N;
+    const size_t words = (size_t)count * (dim + 1);
+    uint8_t *d_seeds = nullptr, *d_sbox = nullptr;
+    uint64_t *d_bodies = nullptr, *d_tmp = nullptr;
+    auto cleanup = [&] { (void)hipFree(d_seeds); (void)hipFree(d_sbox); (void)hipFree(d_bodies); (void)hipFree(d_tmp); };
+    hipError_t e = hipMalloc((void**)&d_seeds, (size_t)count * 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_sbox, 256);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_bodies, (size_t)count * 8);
+    if (e == hipSuccess && !d_out) e = hipMalloc((void**)&d_tmp, words * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_seeds, seeds, (size_t)count * 16, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_sbox, aes_sbox(), 256, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_bodies, bodies, (size_t)count * 8, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) { cleanup(); return fail(std::string("expand_seeded_lwe: ") + hipGetErrorString(e)); }
+    uint64_t* target = d_out ? d_out : d_tmp;
+    hipLaunchKernelGGL(seeded_lwe_expand_kernel, dim3(count), dim3(64), 0, stream, d_seeds, d_bodies, d_sbox, target, dim);
+    e = hipGetLastError();
+    if (e == hipSuccess && host_out) e = hipMemcpyAsync(host_out, target, words * 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    cleanup();
+    if (e != hipSuccess) return fail(std::string("expand_seeded_lwe: ") + hipGetErrorString(e));
+    return 0;
+}
+
 // Server-key generation on the device (keygen_kernels.hip.h); replaces ServerKey::new
 // (shortint/engine/server_side.rs:54-160) for callers that hold the secret keys next to the GPU.
 int Engine::generate_keys(const uint64_t* glwe_sk, const uint64_t* small_sk, const uint8_t seed[32],

@@ -94,4 +94,52 @@ __global__ void __launch_bounds__(256) seeded_scatter_bodies_kernel(const uint64
         out[(e / body_per_row) * row_words + mask_per_row + e % body_per_row] = bodies[e];
 }
 
+// Seeded LWE ciphertexts (shortint CompressedCiphertext, one compression seed EACH -- shortint/ciphertext/mod.rs:471-478,
+// seeded_lwe_ciphertext_decompression.rs:11-50): one 64-thread workgroup per ciphertext expands that seed's key
+// schedule in LDS, then its lwe_dim mask words; the body goes last.  An encrypted 256-char string arrives as 94 KB
+// of (seed, body) pairs instead of 16.8 MB of ciphertexts.
+__global__ void __launch_bounds__(64) seeded_lwe_expand_kernel(const uint8_t* __restrict__ seeds /* [count][16] */,
+                                                               const uint64_t* __restrict__ bodies, const uint8_t* __restrict__ sbox_in,
+                                                               uint64_t* __restrict__ out, uint32_t lwe_dim) {
+    __shared__ uint8_t sbox[256];
+    __shared__ uint8_t rk[11][16];
+    for (int i = threadIdx.x; i < 256; i += 64) sbox[i] = sbox_in[i];
+    __syncthreads();
+    const uint32_t ct = blockIdx.x;
+    if (threadIdx.x == 0) {           // AES-128 key schedule of this ciphertext's seed
+        for (int i = 0; i < 16; i++) rk[0][i] = seeds[(size_t)ct * 16 + i];
+        uint8_t rcon = 1;
+        for (int r = 1; r <= 10; r++) {
+            uint8_t t[4] = {sbox[rk[r - 1][13]], sbox[rk[r - 1][14]], sbox[rk[r - 1][15]], sbox[rk[r - 1][12]]};
+            t[0] ^= rcon;
+            rcon = seeded_xtime(rcon);
+            for (int c = 0; c < 4; c++)
+                for (int b = 0; b < 4; b++) rk[r][4 * c + b] = rk[r - 1][4 * c + b] ^ (c == 0 ? t[b] : rk[r][4 * (c - 1) + b]);
+        }
+    }
+    __syncthreads();
+    uint64_t* dst = out + (size_t)ct * (lwe_dim + 1);
+    const uint32_t blocks = (1 + 8 * lwe_dim + 15) / 16;
+    for (uint32_t base = 0; base < blocks; base += 64) {
+        const uint32_t blk = base + threadIdx.x;
+        uint8_t s[16];
+        seeded_aes_block(rk, sbox, blk, s);
+        unsigned next0 = (unsigned)__shfl_down((int)s[0], 1);
+        if (threadIdx.x == 63) {
+            uint8_t nb[16];
+            seeded_aes_block(rk, sbox, (uint64_t)blk + 1, nb);
+            next0 = nb[0];
+        }
+        uint64_t w0 = 0, w1 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) w0 |= (uint64_t)s[1 + i] << (8 * i);
+#pragma unroll
+        for (int i = 0; i < 7; i++) w1 |= (uint64_t)s[9 + i] << (8 * i);
+        w1 |= (uint64_t)(next0 & 0xFF) << 56;
+        if (2 * blk < lwe_dim) dst[2 * blk] = w0;
+        if (2 * blk + 1 < lwe_dim) dst[2 * blk + 1] = w1;
+    }
+    if (threadIdx.x == 0) dst[lwe_dim] = bodies[ct];
+}
+
 }  // namespace fhe

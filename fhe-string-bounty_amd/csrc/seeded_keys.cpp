@@ -424,4 +424,58 @@ int fhe_wire_read_compressed_server_key(const fhe_params_t* p, const uint8_t* in
     return 0;
 }
 
+// Seeded LWE ciphertexts: every ciphertext has its own compression seed (seeded_lwe_ciphertext_decompression.rs:11-50).
+int fhe_seeded_decompress_lwe_batch(uint32_t lwe_dim, const uint8_t* seeds, const uint64_t* bodies, uint32_t count, uint64_t* out) {
+    if (count && (!seeds || !bodies || !out)) return fail("null pointer");
+    for (uint32_t c = 0; c < count; c++) {
+        MaskStream s(seeds + (size_t)c * 16);
+        uint64_t* ct = out + (size_t)c * (lwe_dim + 1);
+        s.words(ct, lwe_dim);
+        ct[lwe_dim] = bodies[c];
+    }
+    return 0;
+}
+
+// shortint CompressedCiphertext { ct: SeededLweCiphertext { data: u64, lwe_size, compression_seed, ciphertext_modulus },
+// degree, message_modulus, carry_modulus, pbs_order, noise_level }   shortint/ciphertext/mod.rs:471-478,
+// entities/seeded_lwe_ciphertext.rs:13-18 -- note the field order differs from shortint::Ciphertext's
+int fhe_wire_write_compressed_ciphertext(uint64_t body, size_t lwe_size, const uint8_t seed[16], const fhe_shortint_meta* meta,
+                                         uint8_t* out, size_t out_cap, size_t* written) {
+    if (!seed || !meta) return fail("null pointer");
+    Writer w{out, out_cap};
+    w.u64(body);
+    w.u64(lwe_size);
+    w.bytes(seed, 16);
+    w.native_modulus_u64();
+    w.u64(meta->degree);
+    w.u64(meta->message_modulus);
+    w.u64(meta->carry_modulus);
+    for (int i = 0; i < 4; i++) { const uint8_t b = (uint8_t)(meta->pbs_order >> (8 * i)); w.bytes(&b, 1); }
+    w.u64(meta->noise_level);
+    return finish(w, written);
+}
+
+int fhe_wire_read_compressed_ciphertext(const uint8_t* in, size_t in_len, uint64_t* body, size_t* lwe_size, uint8_t seed[16],
+                                        fhe_shortint_meta* meta, size_t* consumed) {
+    if (!in || !body || !seed || !meta) return fail("null pointer");
+    Reader r{in, in_len};
+    *body = r.u64();
+    const uint64_t size = r.u64();
+    r.raw(seed, 16);
+    r.native_modulus_u64();
+    meta->degree = r.u64();
+    meta->message_modulus = r.u64();
+    meta->carry_modulus = r.u64();
+    uint8_t ob[4] = {0, 0, 0, 0};
+    r.raw(ob, 4);
+    meta->noise_level = r.u64();
+    if (!r.err.empty()) return fail("CompressedCiphertext: " + r.err);
+    meta->pbs_order = (uint32_t)ob[0] | (uint32_t)ob[1] << 8 | (uint32_t)ob[2] << 16 | (uint32_t)ob[3] << 24;
+    if (meta->pbs_order > 1) return fail("CompressedCiphertext: unknown PBSOrder " + std::to_string(meta->pbs_order));
+    if (size == 0) return fail("CompressedCiphertext: lwe_size 0");
+    if (lwe_size) *lwe_size = (size_t)size;
+    if (consumed) *consumed = r.pos;
+    return 0;
+}
+
 }  // extern "C"

@@ -140,6 +140,8 @@ EXPORTS = [
     "fhe_wire_write_seeded_keyswitch_key", "fhe_wire_read_seeded_keyswitch_key", "fhe_wire_write_seeded_bootstrap_key",
     "fhe_wire_read_seeded_bootstrap_key", "fhe_wire_write_multi_bit_bootstrap_key", "fhe_wire_read_multi_bit_bootstrap_key",
     "fhe_wire_write_compressed_server_key", "fhe_wire_read_compressed_server_key",
+    "fhe_engine_expand_seeded_lwe", "fhe_seeded_decompress_lwe_batch", "fhe_wire_write_compressed_ciphertext",
+    "fhe_wire_read_compressed_ciphertext",
     "fhe_plan_create", "fhe_plan_destroy", "fhe_plan_input", "fhe_plan_lut", "fhe_plan_lin", "fhe_plan_pbs",
     "fhe_plan_output", "fhe_plan_finalize", "fhe_plan_info", "fhe_plan_level_info", "fhe_plan_export_level",
     "fhe_plan_run", "fhe_plan_run_level_rank_dev", "fhe_plan_gather_outputs_dev", "fhe_str_plan_create",
@@ -197,6 +199,7 @@ def lib() -> C.CDLL:
     sig("fhe_engine_set_variant", vp, i32)
     sig("fhe_engine_set_multibit_combine_max", vp, u32)
     sig("fhe_engine_load_seeded_keys", vp, vp, vp, vp, vp, vp, vp)
+    sig("fhe_engine_expand_seeded_lwe", vp, vp, vp, u32, vp, vp)
     sig("fhe_lut_generate", vp, vp, C.POINTER(u32), C.POINTER(C.c_uint64))
     sig("fhe_lut_upload", vp, vp, C.POINTER(u32))
     sig("fhe_lut_download", vp, u32, vp)
@@ -342,6 +345,19 @@ class Engine:
         _check(lib().fhe_engine_load_seeded_keys(self._h, seeds[0], _ptr(kb), seeds[1], _ptr(bb),
                                                  _ptr(bsk) if export else None, _ptr(ksk) if export else None))
         return (bsk, ksk) if export else None
+
+    def expand_seeded_lwe(self, seeds, bodies, d_out: int | None = None):
+        """Compressed ciphertexts (one 16-byte compression seed and one body each; shortint CompressedCiphertext) ->
+        full big-key ciphertexts, masks generated on the GPU.  d_out: device pointer to write them to (count x
+        big_size words) instead of returning a host array."""
+        seeds = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint8).reshape(-1, 16))
+        bodies = _u64(bodies)
+        if seeds.shape[0] != bodies.size:
+            raise FheError("one seed per body")
+        out = None if d_out else np.zeros((bodies.size, self.params.big_size), dtype=np.uint64)
+        _check(lib().fhe_engine_expand_seeded_lwe(self._h, seeds.ctypes.data_as(C.c_void_p), _ptr(bodies), bodies.size,
+                                                  C.c_void_p(d_out) if d_out else None, _ptr(out) if out is not None else None))
+        return out
 
     def set_multibit_combine_max(self, max_batch: int):
         """Multi-bit PBS: batches up to max_batch prepare their GGSWs on the whole GPU first (0 = always fused)."""

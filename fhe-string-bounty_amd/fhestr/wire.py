@@ -51,6 +51,9 @@ def _sigs():
             ("fhe_wire_read_seeded_bootstrap_key", [PP, vp, sz, vp, vp, szp]),
             ("fhe_wire_write_compressed_server_key", [PP, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, sz, szp]),
             ("fhe_wire_read_compressed_server_key", [PP, vp, sz, vp, vp, vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), szp]),
+            ("fhe_seeded_decompress_lwe_batch", [C.c_uint32, vp, vp, C.c_uint32, vp]),
+            ("fhe_wire_write_compressed_ciphertext", [C.c_uint64, sz, vp, C.POINTER(_Meta), vp, sz, szp]),
+            ("fhe_wire_read_compressed_ciphertext", [vp, sz, C.POINTER(C.c_uint64), szp, vp, C.POINTER(_Meta), szp]),
             ("fhe_wire_write_multi_bit_bootstrap_key", [PP, vp, vp, sz, szp]),
             ("fhe_wire_read_multi_bit_bootstrap_key", [PP, vp, sz, vp, szp]),
             ("fhe_wire_write_shortint_ciphertext", [vp, sz, C.POINTER(_Meta), C.c_int, vp, sz, szp]),
@@ -251,3 +254,25 @@ def read_compressed_server_key(params: Params, data: bytes) -> dict:
                                                        C.byref(deg), C.byref(order), C.byref(used)))
     return {"ksk_seed": bytes(ks), "ksk_bodies": kb, "bsk_seed": bytes(bs), "bsk_bodies": bb, "max_degree": deg.value,
             "pbs_order": order.value, "consumed": used.value}
+
+
+def decompress_lwe_batch(lwe_dim: int, seeds, bodies) -> np.ndarray:
+    """Host-side expansion of seeded LWE ciphertexts (one seed each): (count, lwe_dim + 1)."""
+    seeds = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint8).reshape(-1, 16))
+    bodies = _u64(bodies)
+    out = np.zeros((bodies.size, lwe_dim + 1), dtype=np.uint64)
+    _check(_sigs().fhe_seeded_decompress_lwe_batch(lwe_dim, seeds.ctypes.data_as(C.c_void_p), _ptr(bodies), bodies.size, _ptr(out)))
+    return out
+
+
+def write_compressed_ciphertext(body: int, lwe_size: int, seed, meta: ShortintMeta) -> bytes:
+    """shortint CompressedCiphertext (shortint/ciphertext/mod.rs:471-478)."""
+    m, sd = _Meta(meta.degree, meta.noise_level, meta.message_modulus, meta.carry_modulus, meta.pbs_order), _seed16(seed)
+    return _write(lambda out, cap, n: _sigs().fhe_wire_write_compressed_ciphertext(int(body), lwe_size, sd, C.byref(m), out, cap, n))
+
+
+def read_compressed_ciphertext(data: bytes):
+    """-> (body, lwe_size, seed bytes, ShortintMeta, bytes consumed)"""
+    body, size, used, sd, m = C.c_uint64(), C.c_size_t(), C.c_size_t(), (C.c_uint8 * 16)(), _Meta()
+    _check(_sigs().fhe_wire_read_compressed_ciphertext(_in(data), len(data), C.byref(body), C.byref(size), sd, C.byref(m), C.byref(used)))
+    return body.value, size.value, bytes(sd), ShortintMeta(m.degree, m.noise_level, m.message_modulus, m.carry_modulus, m.pbs_order), used.value

@@ -360,6 +360,18 @@ int fhe_wire_read_shortint_ciphertext(const uint8_t *in, size_t in_len, int safe
 int fhe_engine_load_seeded_keys(fhe_engine *eng, const uint8_t ksk_seed[16], const uint64_t *ksk_bodies,
                                 const uint8_t bsk_seed[16], const uint64_t *bsk_bodies, uint64_t *bsk_std_out,
                                 uint64_t *ksk_out);
+/* Compressed ciphertexts (shortint CompressedCiphertext: a body and a compression seed EACH, 92 bytes on the wire
+ * instead of 8 (kN+1); shortint/ciphertext/mod.rs:471-478, seeded_lwe_ciphertext_decompression.rs): expanded on the
+ * GPU into d_out (device, count x (kN+1) words; may be NULL) and / or host_out.  fhe_seeded_decompress_lwe_batch is
+ * the host-side twin (any LWE dimension). */
+int fhe_engine_expand_seeded_lwe(fhe_engine *eng, const uint8_t *seeds /* [count][16] */, const uint64_t *bodies,
+                                 uint32_t count, uint64_t *d_out, uint64_t *host_out);
+int fhe_seeded_decompress_lwe_batch(uint32_t lwe_dim, const uint8_t *seeds, const uint64_t *bodies, uint32_t count,
+                                    uint64_t *out);
+int fhe_wire_write_compressed_ciphertext(uint64_t body, size_t lwe_size, const uint8_t seed[16], const fhe_shortint_meta *meta,
+                                         uint8_t *out, size_t out_cap, size_t *written);
+int fhe_wire_read_compressed_ciphertext(const uint8_t *in, size_t in_len, uint64_t *body, size_t *lwe_size, uint8_t seed[16],
+                                        fhe_shortint_meta *meta, size_t *consumed);
 int fhe_aes128_encrypt_block(const uint8_t key[16], const uint8_t in[16], uint8_t out[16]);
 int fhe_seeded_mask_words(const uint8_t seed[16], uint64_t *out, size_t count);
 int fhe_seeded_decompress_keyswitch_key(const fhe_params_t *p, const uint8_t seed[16], const uint64_t *bodies, uint64_t *ksk);

@@ -206,6 +206,42 @@ def test_compressed_server_key_container():
             wire.read_compressed_server_key(fp, blob[:-1])
 
 
+def _compress(ck, cts, seeds):
+    """Seeded twins of big-key ciphertexts: body' = body - <mask, s> + <mask(seed), s> (one seed per ciphertext)."""
+    p = ck.params
+    cts = np.asarray(cts, dtype=np.uint64).reshape(-1, p.big_size)
+    s = ck.big_sk
+    bodies = np.zeros(len(cts), dtype=np.uint64)
+    for i, (ct, seed) in enumerate(zip(cts, seeds)):
+        new_mask = _mask_words(seed, p.big_dim)
+        with np.errstate(over="ignore"):          # arithmetic mod 2^64 on numpy scalars
+            bodies[i] = ct[p.big_dim] - (ct[:p.big_dim] * s).sum(dtype=np.uint64) + (new_mask * s).sum(dtype=np.uint64)
+    return bodies
+
+
+def test_compressed_ciphertexts_decompress_and_decrypt():
+    from fhestr import wire
+    p = TOY
+    ck = O.ClientKey(p, 0xC0)
+    M = p.msg_mod * p.carry_mod
+    msgs = list(range(M))
+    seeds = [0x1000 + 77 * i for i in range(M)]
+    bodies = _compress(ck, ck.encrypt_many(msgs), seeds)
+    seed_bytes = np.frombuffer(b"".join(s.to_bytes(16, "little") for s in seeds), dtype=np.uint8).reshape(-1, 16)
+    cts = wire.decompress_lwe_batch(p.big_dim, seed_bytes, bodies)
+    assert np.array_equal(cts[3, :p.big_dim], _mask_words(seeds[3], p.big_dim))
+    assert np.array_equal(ck.decrypt_many(cts), msgs)
+    # wire form: SeededLweCiphertext { data, lwe_size, compression_seed, ciphertext_modulus }, degree, message_modulus,
+    # carry_modulus, pbs_order, noise_level -- 92 bytes
+    meta = wire.ShortintMeta(degree=3, noise_level=1, message_modulus=4, carry_modulus=4, pbs_order=0)
+    blob = wire.write_compressed_ciphertext(int(bodies[5]), p.big_size, seeds[5], meta)
+    assert blob == struct.pack("<QQ", int(bodies[5]), p.big_size) + seeds[5].to_bytes(16, "little") + struct.pack("<QQQ", 0, 0, 64) + \
+        struct.pack("<QQQ", 3, 4, 4) + struct.pack("<I", 0) + struct.pack("<Q", 1)
+    assert len(blob) == 92
+    body, size, sd, m2, used = wire.read_compressed_ciphertext(blob + b"xx")
+    assert (body, size, sd, used) == (int(bodies[5]), p.big_size, seeds[5].to_bytes(16, "little"), 92) and m2 == meta
+
+
 @pytest.mark.gpu
 def test_gpu_expands_seeded_keys_like_the_host_and_bootstraps():
     """fhe_engine_load_seeded_keys: masks from the GPU's AES counter-mode kernel == host decompression, bit for bit
@@ -242,3 +278,31 @@ def test_gpu_expands_seeded_keys_like_the_host_and_bootstraps():
             assert np.array_equal(bsk, wire.decompress_bootstrap_key(P, (1 << 127) + 5, bb))
         finally:
             eng.close()
+
+
+@pytest.mark.gpu
+def test_gpu_expands_compressed_ciphertexts_and_compares_a_compressed_string():
+    """An encrypted string arrives as (seed, body) pairs; the GPU regenerates the masks (== host expansion) and
+    FheString::eq runs on the result."""
+    import fhestr
+    from fhestr import wire
+    from conftest import gpu_engine, keyset
+    ks = keyset(O.TOY_K1)
+    eng = gpu_engine(ks)
+    p, ck = ks.params, ks.ck
+    ops = fhestr.FheStringOps(eng)
+    a, b = b"seeded!", b"seeded?"
+    blocks = lambda s: fhestr.string_to_blocks(eng.params, s, 8)
+    rng = np.random.default_rng(4)
+    got = {}
+    for name, text in (("a", a), ("a2", a), ("b", b)):
+        cts = ck.encrypt_many(blocks(text))
+        seeds = [int(x) for x in rng.integers(1, 1 << 62, size=len(cts))]
+        bodies = _compress(ck, cts, seeds)
+        sb = np.frombuffer(b"".join(s.to_bytes(16, "little") for s in seeds), dtype=np.uint8).reshape(-1, 16)
+        dev = eng.expand_seeded_lwe(sb, bodies)
+        assert np.array_equal(dev, wire.decompress_lwe_batch(p.big_dim, sb, bodies))
+        assert np.array_equal(ck.decrypt_many(dev), blocks(text))
+        got[name] = dev
+    dec = lambda ct: int(ck.decrypt_many(np.asarray(ct).reshape(-1, p.big_size))[0])
+    assert dec(ops.eq(got["a"], got["a2"])) == 1 and dec(ops.eq(got["a"], got["b"])) == 0
