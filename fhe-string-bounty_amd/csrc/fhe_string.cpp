@@ -50,6 +50,15 @@ public:
     };
     // ---- noise: split a sum into pieces one lookup may take (value bound max_terms, noise budget) ----
     double budget() const { return c.noise_budget() > 0 ? c.noise_budget() : 1e300; }
+    // A whole character as ONE lookup input, hi * M + lo: needs two blocks per char whose 8 bits fit the message +
+    // carry space (PARAM_MESSAGE_4_CARRY_4: 4-bit blocks, 256 plaintexts) and 1 + M^2 nominal variances within the
+    // noise budget -- "one PBS per encrypted character".  Per-character predicates and case conversion then cost 1
+    // PBS instead of 3.
+    bool whole_char_fits(const std::vector<uint32_t>& b) const {
+        return bpc == 2 && (uint64_t)M * M <= (uint64_t)T &&
+               c.node(b[0]).noise + (double)M * M * c.node(b[1]).noise <= budget();
+    }
+    uint32_t whole_char(const std::vector<uint32_t>& b) { return c.lin({{b[1], (int32_t)M}, {b[0], 1}}); }
     std::vector<std::vector<Term>> term_groups(const std::vector<Term>& terms, size_t max_terms) const {
         std::vector<std::vector<Term>> out;
         double nu = 0;
@@ -433,9 +442,21 @@ public:
             return (uint64_t)(is ? addv : 0);
         });
         const uint32_t half = bpc / 2;   // blocks per nibble (2 for 2-bit blocks)
+        // whole-char form: the block that holds bit 5, already converted
+        const uint32_t Mv = M, shift = blk * bits_per_block;
+        const uint32_t whole_lut = c.lut_fn([=](uint64_t x) {
+            const uint64_t block = (x >> shift) & (Mv - 1);
+            const bool is = x >= lo_first && x <= lo_last;
+            return is ? (to_lower ? block + addv : block - addv) : block;
+        });
         for (uint32_t i = 0; i < s.cap; i++) {
             Scope sc(c, owner_for(i, s.cap));
             const auto& b = s.ch[i];
+            if (whole_char_fits(b)) {
+                const uint32_t converted = c.pbs(whole_char(b), whole_lut);
+                for (uint32_t k = 0; k < bpc; k++) out.push_back(k == blk ? converted : b[k]);
+                continue;
+            }
             std::vector<Term> lo_terms, hi_terms;
             for (uint32_t k = 0; k < half; k++) {
                 lo_terms.push_back({b[k], (int32_t)(1u << (k * bits_per_block))});
@@ -464,9 +485,16 @@ public:
             return (uint64_t)(((a == 1 && (b & 1)) || (a == 2 && (b & 2))) ? 1 : 0);
         });
         const uint32_t half = bpc / 2;
+        const uint32_t whole_lut = c.lut_fn([null_too](uint64_t x) {
+            return (uint64_t)(((x >= 9 && x <= 13) || x == 32 || (null_too && x == 0)) ? 1 : 0);
+        });
         std::vector<uint32_t> out;
         for (uint32_t i = 0; i < s.cap; i++) {
             Scope sc(c, owner_for(i, s.cap));
+            if (whole_char_fits(s.ch[i])) {
+                out.push_back(c.pbs(whole_char(s.ch[i]), whole_lut));
+                continue;
+            }
             std::vector<Term> lo_terms, hi_terms;
             for (uint32_t k = 0; k < half; k++) {
                 lo_terms.push_back({s.ch[i][k], (int32_t)(1u << (k * bits_per_block))});
