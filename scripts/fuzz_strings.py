@@ -1,5 +1,8 @@
 """Randomised differential test of every FheString operation against Python bytes semantics on the GPU
-(toy parameters: a PBS costs ~0.1 ms).  Usage: python scripts/fuzz_strings.py [cases] [seed]"""
+(toy parameters: a PBS costs ~0.1 ms).  Usage: python scripts/fuzz_strings.py [cases] [seed]
+FUZZ_PARAMS=n32768 runs it on 4-bit blocks (msg_mod = carry_mod = 16 on N = 32768, toy n): the whole-character and
+pattern-class circuits of PARAM_MESSAGE_4_CARRY_4."""
+import os
 import sys
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "fhe-string-bounty_amd")
@@ -8,7 +11,7 @@ import fhestr
 
 N_CASES = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-p = O.TOY_K1
+p = O.TOY_N32768 if os.environ.get("FUZZ_PARAMS") == "n32768" else O.TOY_K1
 ck = O.ClientKey(p, 0xF022)
 sk = O.ServerKey(ck, fourier=False)
 P = fhestr.Params(p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, p.ks_base_log, p.ks_level, p.msg_mod, p.carry_mod,
@@ -42,7 +45,7 @@ def check(name, got, want, ctx):
 
 
 for case in range(N_CASES):
-    cap = int(rng.choice([2, 3, 4, 6, 8]))
+    cap = int(rng.choice([2, 3, 4, 6, 8] if p.msg_mod == 4 else [3, 4, 6, 8, 12]))
     a = rand_str(cap)
     # patterns: often substrings of a so that positive cases are frequent
     if len(a) and rng.random() < 0.6:

@@ -282,6 +282,38 @@ def test_string_ops_with_4_bit_blocks_large_n():
     assert ks.ck.decrypt_many(ops.eq(es, es)[None, :])[0] == 1
 
 
+def test_clear_patterns_by_classes_on_4_bit_blocks():
+    """Clear patterns on 4-bit blocks go through the class-doubling matcher (fhe_string.cpp,
+    window_matches_clear_classes): lengths that are and are not powers of two, repeated characters and
+    self-overlapping patterns, present / absent / at both ends; contains, find, replace and strip against Python."""
+    import fhestr
+    ks = keyset(O.TOY_N32768)
+    eng = gpu_engine(ks)
+    ops = fhestr.FheStringOps(eng)
+    P = eng.params
+    dec = lambda ct: ks.ck.decrypt_many(np.asarray(ct).reshape(-1, ks.params.big_size))
+    dec_str = lambda ct: fhestr.blocks_to_string(P, dec(ct))
+    hay = b"the cat on the mat ate the abcabcab"
+    es = ks.ck.encrypt_many(fhestr.string_to_blocks(P, hay, 40))
+    for pat in (b"th", b"the ", b"abcab", b"aa", b"cab", b"the cat on the m", b"zz", b"tab", b"b", b"e the ab"):
+        found = dec(ops.find(es, pat))
+        want = hay.find(pat)
+        assert int(found[0]) == (want >= 0), pat
+        if want >= 0:
+            assert sum(int(d) * P.msg_mod ** i for i, d in enumerate(found[1:])) == want, pat
+        assert int(dec(ops.contains(es, pat))[0]) == (pat in hay), pat
+    # the plan really is the classed one: (1 + log2 len) PBS per position, not one per distinct character
+    n_pbs = fhestr.Plan.string_op(eng, "contains_clear", 40, 0, clear=b"the ").info()["n_pbs"]
+    assert n_pbs < 3 * 40 + 8
+    for frm, to in ((b"the ", b"THAT"), (b"ab", b"xy"), (b"abc", b"ABC"), (b"at", b"AT")):
+        assert dec_str(ops.replace(es, frm, to)) == hay.replace(frm, to), (frm, to)
+    assert dec_str(ops.replace(es, b"the ", b"a ", out_cap=40)) == hay.replace(b"the ", b"a ")
+    bit, rest = ops.strip_prefix(es, b"the cat")
+    assert int(dec(bit)[0]) == 1 and dec_str(rest) == hay[len(b"the cat"):]
+    bit, rest = ops.strip_suffix(es, b"abcab")
+    assert int(dec(bit)[0]) == 1 and dec_str(rest) == hay[:-5]
+
+
 def test_len_rfind_ignore_case_strip_affix(toy_k1):
     import fhestr
     ops = _ops(toy_k1)
