@@ -11,7 +11,7 @@
 
 // bumped whenever a device kernel changes; profiles/r02_counters.json records the revision its
 // rocprofv3 counters were taken on and bench.py only attaches them to a matching build
-#define FHESTR_KERNEL_REVISION "r02.3"
+#define FHESTR_KERNEL_REVISION "r02.4"
 
 namespace fhe {
 
