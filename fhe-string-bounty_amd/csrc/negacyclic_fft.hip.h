@@ -222,6 +222,8 @@ FHE_SWZ(9, 2, 5, 24, 2, 6, 17, 11, 16, 2, 2, 0, 0, 0, 0, 0, 0, 0)
 FHE_SWZ(8, 2, 10, 1, 25, 4, 12, 3, 16, 8, 0, 0, 0, 0, 0, 0, 0, 0)
 FHE_SWZ(7, 2, 2, 4, 10, 25, 1, 5, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0)
 FHE_SWZ(11, 2, 18, 28, 9, 10, 1, 4, 16, 4, 8, 2, 9, 0, 0, 0, 0, 0)
+// (12, 3) -- N = 8192, pbs_seq_kernels.hip.h -- has a conflict-free map too (11, 6, 18, 10, 5, 2, 12, 16, 16, 4, 13, 20), but with it that
+// kernel is slower (22.4 vs 18.6 ms: 36 % of its LDS cycles are conflicts, the address arithmetic and registers cost more)
 // 128 points, 8 per thread, 16 threads per transform, transforms 16 slots (mod 32) apart -- the
 // large-N kernels' sub-transforms.  Derived by hand: the three pass layouts leave address bits
 // {0,1,2,3}, {0,4,5,6} and {3,4,5,6} free across the 16 lanes of a transform; the low four slot bits
