@@ -160,7 +160,7 @@ int fhe_wire_read_keyswitch_key(const fhe_params_t* p, const uint8_t* in, size_t
 
 int fhe_wire_write_bootstrap_key(const fhe_params_t* p, const uint64_t* bsk_std, uint8_t* out, size_t out_cap, size_t* written) {
     if (!p || !bsk_std) return fail("null pointer");
-    if (p->grouping_factor > 1) return fail("multi-bit bootstrap keys have their own container (LweMultiBitBootstrapKey): not covered");
+    if (p->grouping_factor > 1) return fail("multi-bit bootstrap keys have their own container: use fhe_wire_{read,write}_multi_bit_bootstrap_key");
     Writer w{out, out_cap};
     w.vec_u64(bsk_std, (size_t)p->n * p->pbs_level * (p->k + 1) * (p->k + 1) * p->N);
     w.u64((uint64_t)p->k + 1);
@@ -173,7 +173,7 @@ int fhe_wire_write_bootstrap_key(const fhe_params_t* p, const uint64_t* bsk_std,
 
 int fhe_wire_read_bootstrap_key(const fhe_params_t* p, const uint8_t* in, size_t in_len, uint64_t* bsk_std, size_t* consumed) {
     if (!p || !in || !bsk_std) return fail("null pointer");
-    if (p->grouping_factor > 1) return fail("multi-bit bootstrap keys have their own container (LweMultiBitBootstrapKey): not covered");
+    if (p->grouping_factor > 1) return fail("multi-bit bootstrap keys have their own container: use fhe_wire_{read,write}_multi_bit_bootstrap_key");
     const size_t want = (size_t)p->n * p->pbs_level * (p->k + 1) * (p->k + 1) * p->N;
     Reader r{in, in_len};
     const size_t n = r.vec_u64(bsk_std, want);
