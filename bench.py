@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-strings", action="store_true", help="skip the FheString ms/op section")
     ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep")
     ap.add_argument("--no-p44", action="store_true", help="skip the PARAM_MESSAGE_4_CARRY_4 (config 5) section")
+    ap.add_argument("--serial", action="store_true", help="headline without the keyswitch / blind-rotation pipelining")
     return ap.parse_args()
 
 
@@ -416,6 +417,9 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # throughput mode: consecutive steps are independent batches, so the keyswitch of step k+1 may run in the shadow
+    # of the blind rotation of step k (fhe_engine_set_pipeline); the serial figure is reported next to it
+    eng.set_pipeline(not args.serial)
     for _ in range(args.warmup):
         step()
     fence()
@@ -427,6 +431,20 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ks_ms, br_ms, calls = eng.kernel_times(reset=True)
+    eng.set_pipeline(False)
+    serial = None
+    if not args.serial:        # the same steps one after the other (what a single dependent chain of calls gets)
+        n_serial = min(args.steps, 10)
+        step()
+        eng.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_serial):
+            step()
+        eng.synchronize()
+        serial_dt = (time.perf_counter() - t1) / n_serial
+        s_ks, s_br, s_calls = eng.kernel_times(reset=True)
+        serial = {"ms_per_step": serial_dt * 1e3, "pbs_per_s_per_gpu": B / serial_dt,
+                  "kernel_ms": {"keyswitch": s_ks / max(s_calls, 1), "blind_rotate": s_br / max(s_calls, 1)}}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -475,6 +493,10 @@ def main():
                        "batch_per_gpu": B, "params": P.name, "parallelism": f"replicated keys x{world}"},
             "kernel_ms": {"keyswitch": ks_ms / max(calls, 1), "blind_rotate": br_avg_ms, "launches": calls,
                           "kernel_revision": fhestr.kernel_revision()},
+            "pipelined": (None if args.serial else
+                          "keyswitch of step k+1 on a second stream, co-resident with the blind rotation of step k "
+                          "(fhe_engine_set_pipeline); kernel_ms.keyswitch is that 64-register variant's duration while sharing the CUs"),
+            "serial": serial,
             "verified_decrypt": verified,
             **({"rehearsal": "all ranks share GPU 0 (gloo, host-staged gathers): code-path check only, not a measurement"}
                if rehearsal else {}),

@@ -103,6 +103,15 @@ int fhe_engine_expand_seeded_lwe(fhe_engine* eng, const uint8_t* seeds, const ui
     API_END
 }
 
+int fhe_engine_set_pipeline(fhe_engine* eng, int on) {
+    API_BEGIN
+    CHECK_PTR(eng);
+    if (eng->impl->synchronize()) return 1;
+    eng->impl->pipeline = on != 0;
+    return 0;
+    API_END
+}
+
 int fhe_engine_set_multibit_combine_max(fhe_engine* eng, uint32_t max_batch) {
     API_BEGIN
     CHECK_PTR(eng);
@@ -179,7 +188,7 @@ int fhe_ks_pbs_batch_dev(fhe_engine* eng, const uint64_t* d_in, const uint32_t* 
                          uint64_t* d_out, uint32_t count) {
     API_BEGIN
     CHECK_PTR(eng); CHECK_PTR(d_in); CHECK_PTR(d_out);
-    return eng->impl->ks_pbs_dev(d_in, d_lut_idx, d_out, count);
+    return eng->impl->ks_pbs_dev(d_in, d_lut_idx, d_out, count, /*allow_pipeline=*/true);
     API_END
 }
 

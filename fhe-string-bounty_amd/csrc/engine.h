@@ -11,7 +11,7 @@
 
 // bumped whenever a device kernel changes; profiles/r02_counters.json records the revision its
 // rocprofv3 counters were taken on and bench.py only attaches them to a matching build
-#define FHESTR_KERNEL_REVISION "r02.4"
+#define FHESTR_KERNEL_REVISION "r02.5"
 
 namespace fhe {
 
@@ -45,11 +45,17 @@ struct Engine {
     hipStream_t own_stream = nullptr;
     std::map<std::vector<uint64_t>, uint32_t> lut_dedup;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // scratch triple (unused slots of the ring below)
-    std::vector<hipEvent_t> ring;   // 3 events per recorded ks_pbs call
+    std::vector<hipEvent_t> ring;   // 4 events per recorded ks_pbs call
     size_t ring_used = 0;           // calls recorded since the last reset
     const BrVariant* variant = nullptr;       // layout used up to one LWE per CU
     const BrVariant* variant_large = nullptr; // same Fourier-key layout, used for larger batches (may equal variant)
     int cu_count = 256;
+    bool pipeline = false;                    // ks_pbs_dev: keyswitch of call k+1 in the shadow of the blind rotation of call k
+    hipStream_t ks_stream = nullptr;
+    hipEvent_t pipe_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // keyswitch done [slot], blind rotation done [slot]
+    const void* pipe_out[2] = {nullptr, nullptr};
+    size_t pipe_out_bytes[2] = {0, 0};
+    uint64_t pipe_calls = 0;
     uint32_t multibit_combine_max = 64;       // multi-bit PBS: batches up to this size prepare their GGSWs on the whole GPU first
 
     // resident keys / tables
@@ -91,9 +97,9 @@ struct Engine {
     int ensure_batch(uint32_t count);
     int check_lut_idx(const uint32_t* lut_idx, uint32_t count) const;
 
-    int launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t count);
+    int launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t count, hipStream_t on = nullptr, bool shadow = false);
     int launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx, uint64_t* d_big, uint32_t count);
-    int ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint64_t* d_big_out, uint32_t count);
+    int ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint64_t* d_big_out, uint32_t count, bool allow_pipeline = false);
     int ks_pbs_host(const uint64_t* in, const uint32_t* lut_idx, uint64_t* out, uint32_t count);
     int keyswitch_host(const uint64_t* in, uint64_t* out_small, uint32_t count);
     int pbs_host(const uint64_t* in_small, const uint32_t* lut_idx, uint64_t* out, uint32_t count);

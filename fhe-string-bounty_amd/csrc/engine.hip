@@ -280,11 +280,14 @@ Engine::~Engine() {
     rel(d_pool); rel(d_meta); rel(d_ws); rel(d_slot_exp);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ring) if (e) (void)hipEventDestroy(e);
+    for (auto& e : pipe_ev) if (e) (void)hipEventDestroy(e);
+    if (ks_stream) (void)hipStreamDestroy(ks_stream);
     if (own_stream) (void)hipStreamDestroy(own_stream);
 }
 
 int Engine::set_stream(hipStream_t s, bool use_own) {
     if (use()) return 1;
+    if (ks_stream) HIP_TRY(hipStreamSynchronize(ks_stream));
     HIP_TRY(hipStreamSynchronize(stream));
     stream = use_own ? own_stream : s;   // s == nullptr is HIP's default (null) stream
     return 0;
@@ -615,23 +618,31 @@ int Engine::ensure_batch(uint32_t count) {
     return 0;
 }
 
-int Engine::launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t count) {
+int Engine::launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t count, hipStream_t on, bool shadow) {
     if (!d_ksk && !d_ksk_packed) return fail("keys not loaded");
+    hipStream_t s = on ? on : stream;
     // grid.y = sample tiles; HIP caps grid.y at 65535
     if (count > 65535u * KSD_S) return fail("batch too large for one keyswitch launch (max 524280 LWEs)");
     const uint32_t in_dim = p.k * p.N, out_size = p.n + 1;
-    HIP_TRY(hipMemsetAsync(d_sm, 0, (size_t)count * out_size * 8, stream));
+    HIP_TRY(hipMemsetAsync(d_sm, 0, (size_t)count * out_size * 8, s));
     if (d_ksk_packed) {
         KeyswitchPackedArgs pa{d_big, d_ksk_packed, d_sm, in_dim, out_size, p.ks_base_log, p.ks_level, count};
+        if (shadow) {     // small-register variant: co-resident with the blind rotation of the previous batch
+            constexpr int S = 4;
+            dim3 pgrid((out_size + KS_COLS - 1) / KS_COLS, (count + S - 1) / S, (in_dim + KS_IC - 1) / KS_IC);
+            hipLaunchKernelGGL((keyswitch_dot4_kernel<S, 8>), pgrid, dim3(KS_COLS), (size_t)KS_IC * p.ks_level * S, s, pa);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
         dim3 pgrid((out_size + KS_COLS - 1) / KS_COLS, (count + KSD_S - 1) / KSD_S, (in_dim + KS_IC - 1) / KS_IC);
-        hipLaunchKernelGGL(keyswitch_dot4_kernel, pgrid, dim3(KS_COLS), (size_t)KS_IC * p.ks_level * KSD_S, stream, pa);
+        hipLaunchKernelGGL((keyswitch_dot4_kernel<KSD_S, 2>), pgrid, dim3(KS_COLS), (size_t)KS_IC * p.ks_level * KSD_S, s, pa);
         HIP_TRY(hipGetLastError());
         return 0;
     }
     KeyswitchArgs a{d_big, d_ksk, d_sm, in_dim, out_size, p.ks_base_log, p.ks_level, count};
     dim3 grid((out_size + KS_COLS - 1) / KS_COLS, (count + KS_S - 1) / KS_S, (in_dim + KS_IC - 1) / KS_IC);
     const size_t lds = (size_t)KS_IC * p.ks_level * KS_S;
-    hipLaunchKernelGGL(keyswitch_kernel, grid, dim3(KS_COLS), lds, stream, a);
+    hipLaunchKernelGGL(keyswitch_kernel, grid, dim3(KS_COLS), lds, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -718,7 +729,7 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
 }
 
 int Engine::ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint64_t* d_big_out,
-                       uint32_t count) {
+                       uint32_t count, bool allow_pipeline) {
     if (use()) return 1;
     if (count == 0) return 0;
     const size_t small = (size_t)p.n + 1;
@@ -726,16 +737,55 @@ int Engine::ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint
     // HIP events on the launch stream: per-call kernel durations without host synchronisation
     constexpr size_t RING = 1024;
     if (ring.empty()) {
-        ring.resize(RING * 3);
+        ring.resize(RING * 4);
         for (auto& e : ring) HIP_TRY(hipEventCreate(&e));
     }
-    hipEvent_t* e3 = &ring[(ring_used % RING) * 3];
+    hipEvent_t* e4 = &ring[(ring_used % RING) * 4];     // keyswitch start / end, blind rotation start / end
     ring_used++;
-    HIP_TRY(hipEventRecord(e3[0], stream));
+    if (allow_pipeline && pipeline && stream == own_stream && !variant->large && !variant->wide && !variant->extprod_fn &&
+        count <= (uint32_t)cu_count) {
+        // Pipelined mode (fhe_engine_set_pipeline): the keyswitch of this call runs on a second stream, in a 64-VGPR
+        // variant whose waves fit next to the two 220-VGPR waves per SIMD of the blind rotation still running for the
+        // previous call, into the other of two small-ciphertext buffers.  Calls are independent unless this call's
+        // input overlaps the previous call's output (older outputs are ordered by the buffer hand-over below).
+        if (!ks_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&ks_stream, hipStreamNonBlocking));
+            for (auto& e : pipe_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        if (ensure((void**)&d_small2, &cap_small2, count * small * 8)) return 1;
+        const int slot = (int)(pipe_calls & 1);
+        uint64_t* sm = slot ? d_small2 : d_small;
+        const size_t big = (size_t)p.k * p.N + 1;
+        const char *in_lo = (const char*)d_big_in, *in_hi = in_lo + (size_t)count * big * 8;
+        const char* prev = (const char*)pipe_out[slot ^ 1];
+        if (pipe_calls >= 1 && prev && in_lo < prev + pipe_out_bytes[slot ^ 1] && prev < in_hi)
+            HIP_TRY(hipStreamWaitEvent(ks_stream, pipe_ev[2 + (slot ^ 1)], 0));              // chained: input = previous output
+        if (pipe_calls >= 2) HIP_TRY(hipStreamWaitEvent(ks_stream, pipe_ev[2 + slot], 0));    // blind rotation that read `sm` two calls ago
+        HIP_TRY(hipEventRecord(e4[0], ks_stream));
+        if (launch_keyswitch(d_big_in, sm, count, ks_stream, true)) return 1;
+        HIP_TRY(hipEventRecord(e4[1], ks_stream));
+        HIP_TRY(hipEventRecord(pipe_ev[slot], ks_stream));
+        HIP_TRY(hipStreamWaitEvent(stream, pipe_ev[slot], 0));
+        HIP_TRY(hipEventRecord(e4[2], stream));
+        if (launch_blind_rotate(sm, d_lut_idx, d_big_out, count)) return 1;
+        HIP_TRY(hipEventRecord(e4[3], stream));
+        HIP_TRY(hipEventRecord(pipe_ev[2 + slot], stream));
+        pipe_out[slot] = d_big_out;
+        pipe_out_bytes[slot] = (size_t)count * big * 8;
+        pipe_calls++;
+        return 0;
+    }
+    if (ks_stream && pipe_calls) {        // a serial call after pipelined ones: the shadow keyswitches must be done with d_small
+        HIP_TRY(hipStreamSynchronize(ks_stream));
+        pipe_calls = 0;
+        pipe_out[0] = pipe_out[1] = nullptr;
+    }
+    HIP_TRY(hipEventRecord(e4[0], stream));
     if (launch_keyswitch(d_big_in, d_small, count)) return 1;
-    HIP_TRY(hipEventRecord(e3[1], stream));
+    HIP_TRY(hipEventRecord(e4[1], stream));
+    HIP_TRY(hipEventRecord(e4[2], stream));
     if (launch_blind_rotate(d_small, d_lut_idx, d_big_out, count)) return 1;
-    HIP_TRY(hipEventRecord(e3[2], stream));
+    HIP_TRY(hipEventRecord(e4[3], stream));
     return 0;
 }
 
@@ -848,23 +898,24 @@ int Engine::lincomb_host(const uint64_t* pool, uint32_t pool_count, const uint32
 int Engine::last_kernel_ms(float ms[2]) {
     if (use()) return 1;
     if (ring_used == 0) return fail("no ks_pbs call recorded");
-    hipEvent_t* e3 = &ring[((ring_used - 1) % 1024) * 3];
-    HIP_TRY(hipEventSynchronize(e3[2]));
-    HIP_TRY(hipEventElapsedTime(&ms[0], e3[0], e3[1]));
-    HIP_TRY(hipEventElapsedTime(&ms[1], e3[1], e3[2]));
+    hipEvent_t* e4 = &ring[((ring_used - 1) % 1024) * 4];
+    HIP_TRY(hipEventSynchronize(e4[3]));
+    HIP_TRY(hipEventElapsedTime(&ms[0], e4[0], e4[1]));
+    HIP_TRY(hipEventElapsedTime(&ms[1], e4[2], e4[3]));
     return 0;
 }
 
 int Engine::kernel_times(double total_ms[2], uint32_t* calls, bool reset) {
     if (use()) return 1;
+    if (ks_stream) HIP_TRY(hipStreamSynchronize(ks_stream));
     HIP_TRY(hipStreamSynchronize(stream));
     const size_t nrec = ring_used < 1024 ? ring_used : 1024;
     total_ms[0] = total_ms[1] = 0.0;
     for (size_t c = 0; c < nrec; c++) {
-        hipEvent_t* e3 = &ring[((ring_used - 1 - c) % 1024) * 3];
+        hipEvent_t* e4 = &ring[((ring_used - 1 - c) % 1024) * 4];
         float a = 0, b = 0;
-        HIP_TRY(hipEventElapsedTime(&a, e3[0], e3[1]));
-        HIP_TRY(hipEventElapsedTime(&b, e3[1], e3[2]));
+        HIP_TRY(hipEventElapsedTime(&a, e4[0], e4[1]));
+        HIP_TRY(hipEventElapsedTime(&b, e4[2], e4[3]));
         total_ms[0] += a;
         total_ms[1] += b;
     }
@@ -881,6 +932,7 @@ extern "C" int fhe_debug_read_stamps(unsigned long long* out, size_t count) {
 
 int Engine::synchronize() {
     if (use()) return 1;
+    if (ks_stream) HIP_TRY(hipStreamSynchronize(ks_stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return 0;
 }

@@ -140,7 +140,12 @@ struct KeyswitchPackedArgs {
     uint32_t in_dim, out_size, base_log, level, batch;
 };
 
-__global__ void __launch_bounds__(KS_COLS, 2) keyswitch_dot4_kernel(KeyswitchPackedArgs a) {
+// KSD_S_ = 8 / MINW = 2: the stand-alone kernel.  KSD_S_ = 4 / MINW = 7 (<= 72 VGPRs): a wave of it fits next to the two
+// 220-VGPR waves the blind rotation keeps on every SIMD, so the keyswitch of batch k+1 can run in the shadow of the
+// blind rotation of batch k (Engine::ks_pbs_dev, pipelined mode).
+template <int KSD_S_, int MINW>
+__global__ void __launch_bounds__(KS_COLS, MINW) keyswitch_dot4_kernel(KeyswitchPackedArgs a) {
+    constexpr int KSD_S = KSD_S_;
     extern __shared__ __align__(16) unsigned char ks_smem[];   // [rows/4][KSD_S] u32: 4 biased digits each
     uint32_t* dig = reinterpret_cast<uint32_t*>(ks_smem);
     const uint32_t col = blockIdx.x * KS_COLS + threadIdx.x;

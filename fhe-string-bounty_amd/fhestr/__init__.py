@@ -125,7 +125,7 @@ _lib = None
 EXPORTS = [
     "fhe_last_error", "fhe_kernel_revision", "fhe_engine_create", "fhe_engine_destroy", "fhe_engine_params",
     "fhe_engine_load_keys", "fhe_engine_generate_keys", "fhe_engine_stream", "fhe_engine_synchronize", "fhe_engine_set_variant",
-    "fhe_engine_set_multibit_combine_max", "fhe_engine_load_seeded_keys",
+    "fhe_engine_set_multibit_combine_max", "fhe_engine_load_seeded_keys", "fhe_engine_set_pipeline",
     "fhe_lut_generate", "fhe_lut_upload", "fhe_lut_download", "fhe_lut_count",
     "fhe_keyswitch_batch", "fhe_pbs_batch", "fhe_ks_pbs_batch", "fhe_ks_pbs_batch_dev", "fhe_pbs_ks_batch",
     "fhe_lwe_lincomb_batch", "fhe_last_kernel_ms", "fhe_kernel_times",
@@ -198,6 +198,7 @@ def lib() -> C.CDLL:
     sig("fhe_engine_synchronize", vp)
     sig("fhe_engine_set_variant", vp, i32)
     sig("fhe_engine_set_multibit_combine_max", vp, u32)
+    sig("fhe_engine_set_pipeline", vp, i32)
     sig("fhe_engine_load_seeded_keys", vp, vp, vp, vp, vp, vp, vp)
     sig("fhe_engine_expand_seeded_lwe", vp, vp, vp, u32, vp, vp)
     sig("fhe_lut_generate", vp, vp, C.POINTER(u32), C.POINTER(C.c_uint64))
@@ -358,6 +359,11 @@ class Engine:
         _check(lib().fhe_engine_expand_seeded_lwe(self._h, seeds.ctypes.data_as(C.c_void_p), _ptr(bodies), bodies.size,
                                                   C.c_void_p(d_out) if d_out else None, _ptr(out) if out is not None else None))
         return out
+
+    def set_pipeline(self, on: bool):
+        """Throughput mode for back-to-back apply_lookup_table_dev calls: the keyswitch of call k+1 runs in the shadow
+        of the blind rotation of call k (include/fhestr.h, fhe_engine_set_pipeline)."""
+        _check(lib().fhe_engine_set_pipeline(self._h, int(bool(on))))
 
     def set_multibit_combine_max(self, max_batch: int):
         """Multi-bit PBS: batches up to max_batch prepare their GGSWs on the whole GPU first (0 = always fused)."""

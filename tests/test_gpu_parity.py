@@ -382,3 +382,43 @@ def test_p22_device_key_generation_matches_cpu_keys(p22):
         assert np.array_equal(p22.ck.decrypt_many(got), (msgs * msgs) % 16)
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_pipelined_calls_are_bit_identical_to_serial_ones(p22):
+    """fhe_engine_set_pipeline: the keyswitch of call k+1 in the shadow of the blind rotation of call k.  Independent
+    batches, a chain (output of one call is the input of the next), and one buffer used for every output: the same
+    ciphertexts bit for bit as with serial calls."""
+    import torch
+    ks = p22
+    eng = gpu_engine(ks)
+    p = ks.params
+    M = p.msg_mod * p.carry_mod
+    lut, _ = eng.generate_lookup_table(lambda x: (3 * x + 1) % M)
+    rng = np.random.default_rng(17)
+    B = 96
+    batches = [torch.from_numpy(ks.ck.encrypt_many(rng.integers(0, M, size=B)).view(np.int64)).cuda() for _ in range(5)]
+    idx = torch.full((B,), int(lut), dtype=torch.int32, device="cuda")
+
+    def run(pipelined):
+        eng.set_pipeline(pipelined)
+        outs = [torch.zeros_like(b) for b in batches]
+        for b, o in zip(batches, outs):                                    # independent
+            eng.apply_lookup_table_dev(b.data_ptr(), idx.data_ptr(), o.data_ptr(), B)
+        chain = [torch.zeros_like(batches[0]) for _ in range(4)]
+        src = batches[0]
+        for c in chain:                                                    # chained: input = previous output
+            eng.apply_lookup_table_dev(src.data_ptr(), idx.data_ptr(), c.data_ptr(), B)
+            src = c
+        same = torch.zeros_like(batches[0])
+        for b in batches:                                                  # every output into one buffer
+            eng.apply_lookup_table_dev(b.data_ptr(), idx.data_ptr(), same.data_ptr(), B)
+        eng.synchronize()
+        eng.set_pipeline(False)
+        return [t.cpu().numpy() for t in outs + chain + [same]]
+
+    serial, piped = run(False), run(True)
+    assert all(np.array_equal(a, b) for a, b in zip(serial, piped))
+    # and a serial call right after pipelined ones still sees a free small-ciphertext buffer
+    got = eng.apply_lookup_table(batches[1].cpu().numpy().view(np.uint64), np.full(B, lut, dtype=np.uint32))
+    assert np.array_equal(got.view(np.int64), serial[1])
