@@ -61,6 +61,7 @@ struct Engine {
     // resident keys / tables
     uint64_t* d_ksk = nullptr;       // reference layout (kept only when the byte-plane path is disabled)
     uint32_t* d_ksk_packed = nullptr; // [rows/4][8][n+1] byte planes for keyswitch_dot4_kernel
+    uint64_t* d_ksk_rowsum = nullptr; // [kN / KS_IC][n+1] sums of every tile's key rows (bias removal)
     double* d_fbsk = nullptr;
     uint64_t* d_luts = nullptr;
     size_t luts_cap = 0;

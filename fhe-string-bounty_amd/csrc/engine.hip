@@ -276,7 +276,7 @@ Engine::~Engine() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     auto rel = [](void* ptr) { if (ptr) (void)hipFree(ptr); };
-    rel(d_ksk); rel(d_ksk_packed); rel(d_fbsk); rel(d_luts); rel(d_in); rel(d_small); rel(d_small2); rel(d_out); rel(d_idx);
+    rel(d_ksk); rel(d_ksk_packed); rel(d_ksk_rowsum); rel(d_fbsk); rel(d_luts); rel(d_in); rel(d_small); rel(d_small2); rel(d_out); rel(d_idx);
     rel(d_pool); rel(d_meta); rel(d_ws); rel(d_slot_exp);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ring) if (e) (void)hipEventDestroy(e);
@@ -540,6 +540,11 @@ int Engine::install_keys(uint64_t* d_ksk_std, uint64_t* d_std) {
         HIP_TRY(hipMalloc((void**)&d_ksk_packed, (size_t)(rows / 4) * 8 * osz * 4));
         hipLaunchKernelGGL(ksk_pack_kernel, dim3((osz + 255) / 256, rows / 4), dim3(256), 0, stream,
                            d_ksk_std, d_ksk_packed, rows, osz);
+        const uint32_t tiles = (p.k * p.N + KS_IC - 1) / KS_IC;
+        if (d_ksk_rowsum) { HIP_TRY(hipFree(d_ksk_rowsum)); d_ksk_rowsum = nullptr; }
+        HIP_TRY(hipMalloc((void**)&d_ksk_rowsum, (size_t)tiles * osz * 8));
+        hipLaunchKernelGGL(ksk_rowsum_kernel, dim3((osz + 255) / 256, tiles), dim3(256), 0, stream,
+                           d_ksk_std, d_ksk_rowsum, rows, osz, (uint32_t)KS_IC * p.ks_level);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
     } else {
@@ -626,7 +631,7 @@ int Engine::launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t cou
     const uint32_t in_dim = p.k * p.N, out_size = p.n + 1;
     HIP_TRY(hipMemsetAsync(d_sm, 0, (size_t)count * out_size * 8, s));
     if (d_ksk_packed) {
-        KeyswitchPackedArgs pa{d_big, d_ksk_packed, d_sm, in_dim, out_size, p.ks_base_log, p.ks_level, count};
+        KeyswitchPackedArgs pa{d_big, d_ksk_packed, d_ksk_rowsum, d_sm, in_dim, out_size, p.ks_base_log, p.ks_level, count};
         if (shadow) {     // small-register variant: co-resident with the blind rotation of the previous batch
             constexpr int S = 4;
             dim3 pgrid((out_size + KS_COLS - 1) / KS_COLS, (count + S - 1) / S, (in_dim + KS_IC - 1) / KS_IC);

@@ -131,11 +131,24 @@ __global__ void __launch_bounds__(256) ksk_pack_kernel(const uint64_t* __restric
     }
 }
 
+// The bias removal needs (beta/2) * sum over the tile's rows of KSK[row][col]: a property of the key alone, summed once
+// at load time instead of eight more dot products per four rows in every launch.
+__global__ void __launch_bounds__(256) ksk_rowsum_kernel(const uint64_t* __restrict__ ksk, uint64_t* __restrict__ rowsum,
+                                                         uint32_t rows, uint32_t out_size, uint32_t rows_per_tile) {
+    const uint32_t col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= out_size) return;
+    const uint32_t r0 = blockIdx.y * rows_per_tile;
+    uint64_t sum = 0;
+    for (uint32_t r = r0; r < r0 + rows_per_tile && r < rows; r++) sum += ksk[(size_t)r * out_size + col];
+    rowsum[(size_t)blockIdx.y * out_size + col] = sum;
+}
+
 constexpr int KSD_S = 8;      // samples per tile of the byte-plane kernel (64 u32 accumulators per thread)
 
 struct KeyswitchPackedArgs {
     const uint64_t* lwe_in;    // [B][in_dim+1]
     const uint32_t* packed;    // [in_dim*level/4][8][out_size]
+    const uint64_t* rowsum;    // [in_dim / KS_IC][out_size]: sum of the tile's key rows (ksk_rowsum_kernel)
     uint64_t* lwe_out;         // [B][out_size], zero-filled before launch
     uint32_t in_dim, out_size, base_log, level, batch;
 };
@@ -183,7 +196,6 @@ __global__ void __launch_bounds__(KS_COLS, MINW) keyswitch_dot4_kernel(Keyswitch
     for (int s = 0; s < KSD_S; s++)
 #pragma unroll
         for (int t = 0; t < 8; t++) acc[s][t] = 0;
-    uint32_t sumk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool col_ok = col < a.out_size;
     const uint32_t ccol = col_ok ? col : 0;
     const uint32_t* kp = a.packed + ((size_t)(i0 * L) / 4) * 8 * a.out_size + ccol;
@@ -199,16 +211,12 @@ __global__ void __launch_bounds__(KS_COLS, MINW) keyswitch_dot4_kernel(Keyswitch
         }
 #pragma unroll
         for (int t = 0; t < 8; t++) {
-            sumk[t] = __builtin_amdgcn_udot4(kb[t], 0x01010101u, sumk[t], false);
 #pragma unroll
             for (int s = 0; s < KSD_S; s++) acc[s][t] = __builtin_amdgcn_udot4(kb[t], dw[s], acc[s][t], false);
         }
     }
     if (!col_ok) return;
-    uint64_t corr = 0;
-#pragma unroll
-    for (int t = 0; t < 8; t++) corr += (uint64_t)sumk[t] << (8 * t);
-    corr *= (uint64_t)half;
+    const uint64_t corr = a.rowsum[(size_t)blockIdx.z * a.out_size + col] * (uint64_t)half;
 #pragma unroll
     for (int s = 0; s < KSD_S; s++) {
         const uint32_t b = b0 + s;
