@@ -504,6 +504,13 @@ def main():
             "batch_sweep_pbs_per_s": sweep,
         }
         rec.update(rooflines(P, B, world, value, br_avg_ms, fhestr.kernel_revision(), args.log2_points))
+        if serial:   # the same kernel when nothing shares the CUs with it (the serial comparison steps)
+            alone = rooflines(P, B, world, value, serial["kernel_ms"]["blind_rotate"], fhestr.kernel_revision(), args.log2_points)
+            rec["roofline"]["kernel_alone"] = {"avg_launch_ms": serial["kernel_ms"]["blind_rotate"], "frac": alone["roofline"]["frac"]}
+            rec["roofline_compute"]["kernel_alone"] = {"avg_launch_ms": serial["kernel_ms"]["blind_rotate"],
+                                                       "frac": alone["roofline_compute"]["frac"]}
+            rec["roofline"]["note"] += "; avg_launch_ms is measured with the next step's keyswitch co-resident (pipelined mode), kernel_alone without"
+
 
     # ---- FheString ms/op (BASELINE.json configs 3 and 4): level batches sharded over the ranks, one
     #      RCCL all-gather per level; single GPU = same code with world 1.  A watchdog makes sure the
