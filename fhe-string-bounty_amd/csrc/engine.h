@@ -56,6 +56,7 @@ struct Engine {
     const void* pipe_out[2] = {nullptr, nullptr};
     size_t pipe_out_bytes[2] = {0, 0};
     uint64_t pipe_calls = 0;
+    int shadow_fit = -1;                      // -1 unknown, else whether a 64-VGPR wave fits next to the rotation's
     uint32_t multibit_combine_max = 64;       // multi-bit PBS: batches up to this size prepare their GGSWs on the whole GPU first
 
     // resident keys / tables
@@ -100,6 +101,7 @@ struct Engine {
 
     int launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t count, hipStream_t on = nullptr, bool shadow = false);
     int launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx, uint64_t* d_big, uint32_t count);
+    bool shadow_keyswitch_fits();
     int ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint64_t* d_big_out, uint32_t count, bool allow_pipeline = false);
     int ks_pbs_host(const uint64_t* in, const uint32_t* lut_idx, uint64_t* out, uint32_t count);
     int keyswitch_host(const uint64_t* in, uint64_t* out_small, uint32_t count);

@@ -319,6 +319,7 @@ int Engine::set_variant(int logR) {
         return fail("variant must be chosen before fhe_engine_load_keys (Fourier key layout depends on it)");
     variant = v;
     variant_large = v;
+    shadow_fit = -1;
     if (logR == 0) {
         const BrVariant* w = find_variant(p, v->logR | 16);
         if (w) variant_large = w;
@@ -733,6 +734,21 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
     return 0;
 }
 
+// Can a 64-register keyswitch wave sit on a SIMD next to the blind rotation's waves?  (one workgroup per CU, its waves
+// spread over the four SIMDs, registers allocated in blocks of 8 out of 512 per SIMD lane)
+bool Engine::shadow_keyswitch_fits() {
+    if (shadow_fit < 0) {
+        hipFuncAttributes fa{};
+        shadow_fit = 0;
+        if (hipFuncGetAttributes(&fa, variant->rotate_fn) == hipSuccess) {
+            const int waves_per_simd = (variant->threads / 64 + 3) / 4;
+            const int regs = (fa.numRegs + 7) / 8 * 8;
+            shadow_fit = waves_per_simd * regs + 64 <= 512 ? 1 : 0;
+        }
+    }
+    return shadow_fit == 1;
+}
+
 int Engine::ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint64_t* d_big_out,
                        uint32_t count, bool allow_pipeline) {
     if (use()) return 1;
@@ -748,7 +764,7 @@ int Engine::ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint
     hipEvent_t* e4 = &ring[(ring_used % RING) * 4];     // keyswitch start / end, blind rotation start / end
     ring_used++;
     if (allow_pipeline && pipeline && stream == own_stream && !variant->large && !variant->wide && !variant->extprod_fn &&
-        count <= (uint32_t)cu_count) {
+        count <= (uint32_t)cu_count && shadow_keyswitch_fits()) {
         // Pipelined mode (fhe_engine_set_pipeline): the keyswitch of this call runs on a second stream, in a 64-VGPR
         // variant whose waves fit next to the two 220-VGPR waves per SIMD of the blind rotation still running for the
         // previous call, into the other of two small-ciphertext buffers.  Calls are independent unless this call's
