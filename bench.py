@@ -35,8 +35,8 @@ SEED = 0x5EED0002
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="LWEs per step per GPU")
     ap.add_argument("--log2-points", type=int, default=0, help="blind-rotate variant (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
