@@ -422,3 +422,58 @@ def test_pipelined_calls_are_bit_identical_to_serial_ones(p22):
     # and a serial call right after pipelined ones still sees a free small-ciphertext buffer
     got = eng.apply_lookup_table(batches[1].cpu().numpy().view(np.uint64), np.full(B, lut, dtype=np.uint32))
     assert np.array_equal(got.view(np.int64), serial[1])
+
+
+@pytest.mark.gpu
+def test_blind_rotation_against_an_exact_integer_recurrence():
+    """Known-answer test of the rotate-subtract-decompose-accumulate chain (polynomial_algorithms.rs:315-354,425-490,
+    decomposer.rs:98-118, bootstrap.rs:242-331) that needs neither the oracle nor its FFT: with an all-zero GLWE
+    secret, noiseless GGSWs are just `bit * q / B` at one coefficient, and the blind rotation of the body polynomial is
+        B <- LUT * X^-ms(b);   B <- B + s_i * closest_representable(B * X^ms(a_i) - B)    for every a_i != 0
+    in exact wrapping integers.  The GPU's f64 path may differ by its transform rounding (a few 2^13 per step) and,
+    rarely, by one decomposition digit (2^41) where that rounding crosses a digit boundary: any indexing or sign
+    mistake in the rotation would be off by ~2^60."""
+    import fhestr
+    P = fhestr.PARAM_MESSAGE_2_CARRY_2_KS_PBS
+    n, N, k, bl = P.n, P.N, P.k, P.pbs_base_log
+    rng = np.random.default_rng(0xA5)
+    s = rng.integers(0, 2, size=n, dtype=np.uint64)
+    bsk = np.zeros((n, 1, k + 1, k + 1, N), dtype=np.uint64)
+    bsk[:, 0, k, k, 0] = s << np.uint64(64 - bl)            # last row, body polynomial, coefficient 0 (ggsw_encryption.rs:122-126)
+    eng = fhestr.Engine(P, 0)
+    try:
+        eng.load_keys(bsk.reshape(-1), np.zeros(P.ksk_len, dtype=np.uint64))
+        lut = np.zeros((k + 1, N), dtype=np.uint64)
+        lut[k] = rng.integers(0, 1 << 63, size=N, dtype=np.uint64) * np.uint64(2)
+        lut_id = eng.upload_lut(lut.reshape(-1))
+        B = 48
+        cts = rng.integers(0, 1 << 63, size=(B, n + 1), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(B, n + 1), dtype=np.uint64)
+        cts[:, 5] = 0                                        # an a_i == 0 is skipped (bootstrap.rs:281)
+        got = eng.pbs(cts, np.full(B, lut_id, dtype=np.uint32))
+
+        def ms(x):                                           # fast_pbs_modulus_switch, common.rs:26-43
+            return ((int(x) >> (64 - 11 - 2)) + 1) >> 1
+        def monomial_mul(p, d):                              # p * X^d mod X^N + 1, d in [0, 2N]
+            d %= 2 * N
+            out = np.roll(p, d % N).copy()
+            out[: d % N] = np.uint64(0) - out[: d % N]
+            return (np.uint64(0) - out) if d >= N else out
+        def closest(x):                                      # decomposer.rs:105-117 for one level of bl bits
+            sh = np.uint64(63 - bl)
+            return (((x >> sh) + np.uint64(1)) & ~np.uint64(1)) << sh
+        worst, off = 0, 0
+        with np.errstate(over="ignore"):
+            for c, out in zip(cts, got):
+                body = monomial_mul(lut[k], 2 * N - ms(c[n]))
+                for i in range(n):
+                    if c[i] == 0 or s[i] == 0:
+                        continue
+                    body = body + closest(monomial_mul(body, ms(c[i])) - body)
+                assert not out[:N].any()                     # the mask polynomial stays zero: sample extraction of zeros
+                d = int(out[N]) - int(body[0])
+                d = abs((d + (1 << 63)) % (1 << 64) - (1 << 63))
+                worst = max(worst, d)
+                off += d > 1 << 26
+        assert worst < 1 << 46 and off <= B // 4, (worst, off)
+    finally:
+        eng.close()
