@@ -460,6 +460,27 @@ def main():
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
         verified = bool(v.item())
 
+    # ---- SURVEY 8(d) config 2, second variant: one shared identity table for the whole batch ----
+    identity = None
+    if world == 1:
+        ident_id, _ = eng.generate_lookup_table(lambda x: x)
+        d_same = torch.full((B,), int(ident_id), dtype=torch.int32, device="cuda")
+        d_id_out = torch.zeros_like(d_in)
+        eng.set_pipeline(not args.serial)
+        for _ in range(3):
+            eng.apply_lookup_table_dev(d_in.data_ptr(), d_same.data_ptr(), d_id_out.data_ptr(), B)
+        eng.synchronize()
+        n_id = min(args.steps, 20)
+        t1 = time.perf_counter()
+        for _ in range(n_id):
+            eng.apply_lookup_table_dev(d_in.data_ptr(), d_same.data_ptr(), d_id_out.data_ptr(), B)
+        eng.synchronize()
+        id_dt = (time.perf_counter() - t1) / n_id
+        eng.set_pipeline(False)
+        eng.kernel_times(reset=True)
+        id_ok = bool(np.array_equal(ck.decrypt(d_id_out.cpu().numpy().view(np.uint64)), msgs))
+        identity = {"pbs_per_s": B / id_dt, "ms_per_step": id_dt * 1e3, "verified_decrypt": id_ok}
+
     # ---- batch-size sweep like the reference's throughput bench (benches/core_crypto/pbs_bench.rs:430-549) ----
     sweep = None
     if world == 1 and not args.no_sweep:
@@ -501,6 +522,7 @@ def main():
             **({"rehearsal": "all ranks share GPU 0 (gloo, host-staged gathers): code-path check only, not a measurement"}
                if rehearsal else {}),
             "string_ops": None,
+            "shared_identity_lut": identity,
             "batch_sweep_pbs_per_s": sweep,
         }
         rec.update(rooflines(P, B, world, value, br_avg_ms, fhestr.kernel_revision(), args.log2_points))
