@@ -446,3 +446,51 @@ def test_string_plans_stay_inside_the_noise_budget():
             ni = plan.noise_info()
             assert 0 < ni["max_pbs_input_noise"] <= ni["budget"], (P.name, op, ni)
             assert ni["log2_pfail_worst"] < -38.5, (P.name, op, ni)
+
+
+# ---- 4-bit blocks (PARAM_MESSAGE_4_CARRY_4 geometry, toy LWE dimension): whole-character lookups and the
+#      class-doubling clear-pattern matcher, plans run by the CPU oracle ---------------------------------------------
+def _plan4(op, a_cap, b_cap=0, clear=None):
+    import fhestr
+    return fhestr.Plan.string_op(None, op, a_cap, b_cap, clear, 1, params=to_fhestr_params(O.TOY_N32768))
+
+
+def test_whole_character_lookups_on_4_bit_blocks():
+    import fhestr
+    ks = keyset(O.TOY_N32768)
+    P = to_fhestr_params(ks.params)
+    s = b"Az [`{@Zq"
+    for op, want in (("to_lower", s.lower()), ("to_upper", s.upper())):
+        plan = _plan4(op, 10)
+        assert plan.info()["n_pbs"] == 10 and plan.info()["n_levels"] == 1        # one PBS per character
+        assert plan.noise_info()["max_pbs_input_noise"] == 257.0                  # hi * 16 + lo of two nominal blocks
+        got = fhestr.blocks_to_string(P, ks.ck.decrypt_many(run_with_oracle(plan, _enc(ks, s, 10), ks.sk)))
+        assert got == want
+    plan = _plan4("strip", 6)
+    got = fhestr.blocks_to_string(P, ks.ck.decrypt_many(run_with_oracle(plan, _enc(ks, b" \tab ", 6), ks.sk)))
+    assert got == b"ab"
+
+
+@pytest.mark.parametrize("hay,pat", [(b"abcabcab", b"abcab"), (b"the cat the", b"the "), (b"aaaaaa", b"aa"), (b"xyzxyz", b"zx"),
+                                     (b"abcdefgh", b"cdefgh"), (b"abcdefgh", b"zz"), (b"aabaab", b"aab")])
+def test_clear_patterns_by_classes_offline_plan_vs_python(hay, pat):
+    import fhestr
+    ks = keyset(O.TOY_N32768)
+    P = to_fhestr_params(ks.params)
+    cap = 12
+    enc = _enc(ks, hay, cap)
+    plan = _plan4("find_clear", cap, 0, pat)
+    out = ks.ck.decrypt_many(run_with_oracle(plan, enc, ks.sk))
+    want = hay.find(pat)
+    assert int(out[0]) == (want >= 0)
+    if want >= 0:
+        assert sum(int(d) * P.msg_mod ** i for i, d in enumerate(out[1:])) == want
+    plan = _plan4("contains_clear", cap, 0, pat)
+    # classify + double: about (1 + ceil(log2 len)) lookups per position, far below one per (position, distinct character)
+    assert plan.info()["n_pbs"] <= cap * (2 + len(pat).bit_length()) + 4
+    assert int(ks.ck.decrypt_many(run_with_oracle(plan, enc, ks.sk))[0]) == (pat in hay)
+    if len(set(pat)) > 1 or len(pat) == 1:
+        to = bytes(reversed(pat)).upper()
+        plan = _plan4("replace_clear", cap, 0, pat + to)
+        got = fhestr.blocks_to_string(P, ks.ck.decrypt_many(run_with_oracle(plan, enc, ks.sk)))
+        assert got == hay.replace(pat, to)
