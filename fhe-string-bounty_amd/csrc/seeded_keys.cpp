@@ -478,4 +478,96 @@ int fhe_wire_read_compressed_ciphertext(const uint8_t* in, size_t in_len, uint64
     return 0;
 }
 
+// integer RadixCiphertext / CompressedRadixCiphertext = BaseRadixCiphertext<Block> { blocks: Vec<Block> }, least significant
+// block first (integer/ciphertext/mod.rs:18-21,30,45): a u64 count, then the blocks -- an FheUint8 character is four of
+// them under PARAM_MESSAGE_2_CARRY_2, a string a sequence of those.
+int fhe_wire_write_radix_ciphertext(const uint64_t* cts, size_t lwe_size, const fhe_shortint_meta* metas, size_t n_blocks,
+                                    uint8_t* out, size_t out_cap, size_t* written) {
+    if ((!cts || !metas) && n_blocks) return fail("null pointer");
+    size_t pos = 0;
+    bool overflow = false;
+    {
+        Writer w{out, out_cap};
+        w.u64(n_blocks);
+        overflow |= w.overflow;
+        pos = w.pos;
+    }
+    for (size_t b = 0; b < n_blocks; b++) {
+        size_t n = 0;
+        const bool have = out && pos < out_cap;
+        if (fhe_wire_write_shortint_ciphertext(cts + b * lwe_size, lwe_size, &metas[b], 0, have ? out + pos : nullptr,
+                                               have ? out_cap - pos : 0, &n)) overflow = true;
+        if (out && !have) overflow = true;
+        pos += n;
+    }
+    if (written) *written = pos;
+    if (out && overflow) return fail("output buffer too small: " + std::to_string(pos) + " bytes needed");
+    return 0;
+}
+
+int fhe_wire_read_radix_ciphertext(const uint8_t* in, size_t in_len, uint64_t* cts, size_t lwe_size, size_t max_blocks,
+                                   fhe_shortint_meta* metas, size_t* n_blocks, size_t* consumed) {
+    if (!in || !cts || !metas || !n_blocks) return fail("null pointer");
+    Reader r{in, in_len};
+    const uint64_t n = r.u64();
+    if (!r.err.empty()) return fail("RadixCiphertext: " + r.err);
+    if (n > max_blocks) return fail("RadixCiphertext: " + std::to_string(n) + " blocks, room for " + std::to_string(max_blocks));
+    size_t pos = r.pos;
+    for (uint64_t b = 0; b < n; b++) {
+        size_t size = 0, used = 0;
+        if (fhe_wire_read_shortint_ciphertext(in + pos, in_len - pos, 0, 0, cts + b * lwe_size, lwe_size, &size, &metas[b], &used)) return 1;
+        if (size != lwe_size) return fail("RadixCiphertext: block " + std::to_string(b) + " has LWE size " + std::to_string(size));
+        pos += used;
+    }
+    *n_blocks = (size_t)n;
+    if (consumed) *consumed = pos;
+    return 0;
+}
+
+int fhe_wire_write_compressed_radix_ciphertext(const uint64_t* bodies, const uint8_t* seeds, size_t lwe_size,
+                                               const fhe_shortint_meta* metas, size_t n_blocks, uint8_t* out, size_t out_cap,
+                                               size_t* written) {
+    if ((!bodies || !seeds || !metas) && n_blocks) return fail("null pointer");
+    size_t pos = 0;
+    bool overflow = false;
+    {
+        Writer w{out, out_cap};
+        w.u64(n_blocks);
+        overflow |= w.overflow;
+        pos = w.pos;
+    }
+    for (size_t b = 0; b < n_blocks; b++) {
+        size_t n = 0;
+        const bool have = out && pos < out_cap;
+        if (fhe_wire_write_compressed_ciphertext(bodies[b], lwe_size, seeds + b * 16, &metas[b], have ? out + pos : nullptr,
+                                                 have ? out_cap - pos : 0, &n)) overflow = true;
+        if (out && !have) overflow = true;
+        pos += n;
+    }
+    if (written) *written = pos;
+    if (out && overflow) return fail("output buffer too small: " + std::to_string(pos) + " bytes needed");
+    return 0;
+}
+
+int fhe_wire_read_compressed_radix_ciphertext(const uint8_t* in, size_t in_len, uint64_t* bodies, uint8_t* seeds, size_t* lwe_size,
+                                              size_t max_blocks, fhe_shortint_meta* metas, size_t* n_blocks, size_t* consumed) {
+    if (!in || !bodies || !seeds || !metas || !n_blocks) return fail("null pointer");
+    Reader r{in, in_len};
+    const uint64_t n = r.u64();
+    if (!r.err.empty()) return fail("CompressedRadixCiphertext: " + r.err);
+    if (n > max_blocks) return fail("CompressedRadixCiphertext: " + std::to_string(n) + " blocks, room for " + std::to_string(max_blocks));
+    size_t pos = r.pos, common = 0;
+    for (uint64_t b = 0; b < n; b++) {
+        size_t size = 0, used = 0;
+        if (fhe_wire_read_compressed_ciphertext(in + pos, in_len - pos, &bodies[b], &size, seeds + b * 16, &metas[b], &used)) return 1;
+        if (b == 0) common = size;
+        else if (size != common) return fail("CompressedRadixCiphertext: blocks of different LWE sizes");
+        pos += used;
+    }
+    *n_blocks = (size_t)n;
+    if (lwe_size) *lwe_size = common;
+    if (consumed) *consumed = pos;
+    return 0;
+}
+
 }  // extern "C"

@@ -141,7 +141,8 @@ EXPORTS = [
     "fhe_wire_read_seeded_bootstrap_key", "fhe_wire_write_multi_bit_bootstrap_key", "fhe_wire_read_multi_bit_bootstrap_key",
     "fhe_wire_write_compressed_server_key", "fhe_wire_read_compressed_server_key",
     "fhe_engine_expand_seeded_lwe", "fhe_seeded_decompress_lwe_batch", "fhe_wire_write_compressed_ciphertext",
-    "fhe_wire_read_compressed_ciphertext",
+    "fhe_wire_read_compressed_ciphertext", "fhe_wire_write_radix_ciphertext", "fhe_wire_read_radix_ciphertext",
+    "fhe_wire_write_compressed_radix_ciphertext", "fhe_wire_read_compressed_radix_ciphertext",
     "fhe_plan_create", "fhe_plan_destroy", "fhe_plan_input", "fhe_plan_lut", "fhe_plan_lin", "fhe_plan_pbs",
     "fhe_plan_output", "fhe_plan_finalize", "fhe_plan_info", "fhe_plan_level_info", "fhe_plan_export_level",
     "fhe_plan_run", "fhe_plan_run_level_rank_dev", "fhe_plan_gather_outputs_dev", "fhe_str_plan_create",

@@ -54,6 +54,10 @@ def _sigs():
             ("fhe_seeded_decompress_lwe_batch", [C.c_uint32, vp, vp, C.c_uint32, vp]),
             ("fhe_wire_write_compressed_ciphertext", [C.c_uint64, sz, vp, C.POINTER(_Meta), vp, sz, szp]),
             ("fhe_wire_read_compressed_ciphertext", [vp, sz, C.POINTER(C.c_uint64), szp, vp, C.POINTER(_Meta), szp]),
+            ("fhe_wire_write_radix_ciphertext", [vp, sz, vp, sz, vp, sz, szp]),
+            ("fhe_wire_read_radix_ciphertext", [vp, sz, vp, sz, sz, vp, szp, szp]),
+            ("fhe_wire_write_compressed_radix_ciphertext", [vp, vp, sz, vp, sz, vp, sz, szp]),
+            ("fhe_wire_read_compressed_radix_ciphertext", [vp, sz, vp, vp, szp, sz, vp, szp, szp]),
             ("fhe_wire_write_multi_bit_bootstrap_key", [PP, vp, vp, sz, szp]),
             ("fhe_wire_read_multi_bit_bootstrap_key", [PP, vp, sz, vp, szp]),
             ("fhe_wire_write_shortint_ciphertext", [vp, sz, C.POINTER(_Meta), C.c_int, vp, sz, szp]),
@@ -276,3 +280,50 @@ def read_compressed_ciphertext(data: bytes):
     body, size, used, sd, m = C.c_uint64(), C.c_size_t(), C.c_size_t(), (C.c_uint8 * 16)(), _Meta()
     _check(_sigs().fhe_wire_read_compressed_ciphertext(_in(data), len(data), C.byref(body), C.byref(size), sd, C.byref(m), C.byref(used)))
     return body.value, size.value, bytes(sd), ShortintMeta(m.degree, m.noise_level, m.message_modulus, m.carry_modulus, m.pbs_order), used.value
+
+
+# ---- integer RadixCiphertext / CompressedRadixCiphertext (integer/ciphertext/mod.rs:18-21,30,45) --------------------
+
+def _metas(metas, n):
+    arr = (_Meta * max(1, n))()
+    for i, m in enumerate(metas):
+        arr[i] = _Meta(m.degree, m.noise_level, m.message_modulus, m.carry_modulus, m.pbs_order)
+    return arr
+
+
+def _metas_out(arr, n):
+    return [ShortintMeta(m.degree, m.noise_level, m.message_modulus, m.carry_modulus, m.pbs_order) for m in arr[:n]]
+
+
+def write_radix_ciphertext(cts, metas) -> bytes:
+    """cts: (n_blocks, lwe_size), least significant block first; one ShortintMeta per block."""
+    cts = np.ascontiguousarray(np.asarray(cts, dtype=np.uint64))
+    n, size = cts.shape
+    m = _metas(metas, n)
+    return _write(lambda out, cap, w: _sigs().fhe_wire_write_radix_ciphertext(_ptr(cts), size, m, n, out, cap, w))
+
+
+def read_radix_ciphertext(data: bytes, lwe_size: int, max_blocks: int = 4096):
+    """-> (cts (n_blocks, lwe_size), [ShortintMeta], bytes consumed)"""
+    cts = np.zeros((max_blocks, lwe_size), dtype=np.uint64)
+    m, n, used = (_Meta * max_blocks)(), C.c_size_t(), C.c_size_t()
+    _check(_sigs().fhe_wire_read_radix_ciphertext(_in(data), len(data), _ptr(cts), lwe_size, max_blocks, m, C.byref(n), C.byref(used)))
+    return cts[:n.value].copy(), _metas_out(m, n.value), used.value
+
+
+def write_compressed_radix_ciphertext(bodies, seeds, lwe_size: int, metas) -> bytes:
+    bodies = _u64(bodies)
+    seeds = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint8).reshape(-1, 16))
+    n = bodies.size
+    m = _metas(metas, n)
+    return _write(lambda out, cap, w: _sigs().fhe_wire_write_compressed_radix_ciphertext(
+        _ptr(bodies), seeds.ctypes.data_as(C.c_void_p), lwe_size, m, n, out, cap, w))
+
+
+def read_compressed_radix_ciphertext(data: bytes, max_blocks: int = 4096):
+    """-> (bodies, seeds (n, 16), lwe_size, [ShortintMeta], bytes consumed): feed bodies / seeds to Engine.expand_seeded_lwe"""
+    bodies, seeds = np.zeros(max_blocks, dtype=np.uint64), np.zeros((max_blocks, 16), dtype=np.uint8)
+    m, n, used, size = (_Meta * max_blocks)(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+    _check(_sigs().fhe_wire_read_compressed_radix_ciphertext(_in(data), len(data), _ptr(bodies), seeds.ctypes.data_as(C.c_void_p),
+                                                             C.byref(size), max_blocks, m, C.byref(n), C.byref(used)))
+    return bodies[:n.value].copy(), seeds[:n.value].copy(), size.value, _metas_out(m, n.value), used.value

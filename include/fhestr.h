@@ -380,6 +380,18 @@ int fhe_wire_write_compressed_ciphertext(uint64_t body, size_t lwe_size, const u
                                          uint8_t *out, size_t out_cap, size_t *written);
 int fhe_wire_read_compressed_ciphertext(const uint8_t *in, size_t in_len, uint64_t *body, size_t *lwe_size, uint8_t seed[16],
                                         fhe_shortint_meta *meta, size_t *consumed);
+/* integer RadixCiphertext / CompressedRadixCiphertext: Vec of blocks, least significant first
+ * (integer/ciphertext/mod.rs:18-21,30,45) -- an FheUint8 character is four blocks under PARAM_MESSAGE_2_CARRY_2. */
+int fhe_wire_write_radix_ciphertext(const uint64_t *cts, size_t lwe_size, const fhe_shortint_meta *metas, size_t n_blocks,
+                                    uint8_t *out, size_t out_cap, size_t *written);
+int fhe_wire_read_radix_ciphertext(const uint8_t *in, size_t in_len, uint64_t *cts, size_t lwe_size, size_t max_blocks,
+                                   fhe_shortint_meta *metas, size_t *n_blocks, size_t *consumed);
+int fhe_wire_write_compressed_radix_ciphertext(const uint64_t *bodies, const uint8_t *seeds /* [n][16] */, size_t lwe_size,
+                                               const fhe_shortint_meta *metas, size_t n_blocks, uint8_t *out, size_t out_cap,
+                                               size_t *written);
+int fhe_wire_read_compressed_radix_ciphertext(const uint8_t *in, size_t in_len, uint64_t *bodies, uint8_t *seeds,
+                                              size_t *lwe_size, size_t max_blocks, fhe_shortint_meta *metas,
+                                              size_t *n_blocks, size_t *consumed);
 int fhe_aes128_encrypt_block(const uint8_t key[16], const uint8_t in[16], uint8_t out[16]);
 int fhe_seeded_mask_words(const uint8_t seed[16], uint64_t *out, size_t count);
 int fhe_seeded_decompress_keyswitch_key(const fhe_params_t *p, const uint8_t seed[16], const uint64_t *bodies, uint64_t *ksk);

@@ -242,6 +242,32 @@ def test_compressed_ciphertexts_decompress_and_decrypt():
     assert (body, size, sd, used) == (int(bodies[5]), p.big_size, seeds[5].to_bytes(16, "little"), 92) and m2 == meta
 
 
+def test_radix_ciphertext_containers():
+    """integer RadixCiphertext / CompressedRadixCiphertext = Vec<block>, least significant block first
+    (integer/ciphertext/mod.rs:18-21,30,45)."""
+    from fhestr import wire, FheError
+    rng = np.random.default_rng(2)
+    size, n = 17, 4
+    cts = rng.integers(0, 1 << 63, size=(n, size), dtype=np.uint64)
+    metas = [wire.ShortintMeta(degree=3, noise_level=1 + i, message_modulus=4, carry_modulus=4, pbs_order=0) for i in range(n)]
+    blob = wire.write_radix_ciphertext(cts, metas)
+    assert blob == struct.pack("<Q", n) + b"".join(wire.write_shortint_ciphertext(c, m) for c, m in zip(cts, metas))
+    got, m2, used = wire.read_radix_ciphertext(blob + b"!", size)
+    assert np.array_equal(got, cts) and m2 == metas and used == len(blob)
+    with pytest.raises(FheError):
+        wire.read_radix_ciphertext(blob, size, max_blocks=3)
+    with pytest.raises(FheError):
+        wire.read_radix_ciphertext(blob, size + 1)
+    bodies = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
+    seeds = rng.integers(0, 256, size=(n, 16), dtype=np.uint8)
+    blob = wire.write_compressed_radix_ciphertext(bodies, seeds, 2049, metas)
+    assert len(blob) == 8 + n * 92
+    b2, s2, lwe_size, m3, used = wire.read_compressed_radix_ciphertext(blob)
+    assert np.array_equal(b2, bodies) and np.array_equal(s2, seeds) and lwe_size == 2049 and m3 == metas and used == len(blob)
+    with pytest.raises(FheError):
+        wire.read_compressed_radix_ciphertext(blob[:-3])
+
+
 @pytest.mark.gpu
 def test_gpu_expands_seeded_keys_like_the_host_and_bootstraps():
     """fhe_engine_load_seeded_keys: masks from the GPU's AES counter-mode kernel == host decompression, bit for bit
