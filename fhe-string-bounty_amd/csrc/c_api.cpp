@@ -121,6 +121,25 @@ int fhe_engine_set_multibit_combine_max(fhe_engine* eng, uint32_t max_batch) {
     API_END
 }
 
+int fhe_engine_set_cluster_mode(fhe_engine* eng, int mode, uint32_t max_batch) {
+    API_BEGIN
+    CHECK_PTR(eng);
+    if (mode < -1 || mode > 1) return fhe::fail("cluster mode: -1 (automatic), 0 (never) or 1 (always)");
+    eng->impl->cluster_mode = mode;
+    eng->impl->cluster_max_batch = max_batch;
+    return 0;
+    API_END
+}
+
+int fhe_engine_cluster_info(fhe_engine* eng, uint32_t* clusters) {
+    API_BEGIN
+    CHECK_PTR(eng); CHECK_PTR(clusters);
+    if (eng->impl->synchronize()) return 1;
+    *clusters = eng->impl->cluster_last;
+    return 0;
+    API_END
+}
+
 int fhe_lut_generate(fhe_engine* eng, const uint64_t* table, uint32_t* lut_id, uint64_t* degree) {
     API_BEGIN
     CHECK_PTR(eng); CHECK_PTR(table); CHECK_PTR(lut_id);

@@ -380,7 +380,7 @@ int Circuit::run_host_parts(const uint64_t* const* parts, const uint32_t* counts
     if (gather_outputs(d_own_pool_, d_own_out_)) return 1;
     HIP_TRY(hipMemcpyAsync(outputs, d_own_out_, (size_t)n_outputs() * big * 8, hipMemcpyDeviceToHost, eng_->stream));
     HIP_TRY(hipStreamSynchronize(eng_->stream));
-    return 0;
+    return eng_->cluster_check();
 }
 
 Circuit::~Circuit() {

@@ -76,6 +76,14 @@ struct Engine {
     void* d_meta = nullptr;
     void* d_ws = nullptr;      // per-LWE HBM workspace of the large-N blind rotation
     size_t cap_ws = 0;
+    void* d_cluster_ws = nullptr;   // cluster kernel: 1.5 MB of exchange matrices per cluster (L2-resident by design)
+    size_t cap_cluster_ws = 0;
+    void* d_cluster_ctl = nullptr;  // ClusterCtl (tickets, flags; zeroed per launch) + ClusterStatus (sticky)
+    bool cluster_unchecked = false; // a cluster launch whose status words have not been read yet
+    uint32_t cluster_last = 0;      // clusters the last checked launch formed
+    int cluster_mode = -1;          // -1 automatic (by batch size), 0 never, 1 always (FHESTR_CLUSTER)
+    uint32_t cluster_max_batch = 0xFFFFFFFFu;
+    int cluster_check();            // after a synchronisation: did a cluster launch give up on a hand-over?
     size_t cap_in = 0, cap_small = 0, cap_small2 = 0, cap_out = 0, cap_idx = 0, cap_pool = 0, cap_meta = 0;
 
     static int create(const fhe_params_t& p, int device, Engine** out);

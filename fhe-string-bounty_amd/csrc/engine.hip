@@ -19,6 +19,7 @@
 #include "lwe_kernels.hip.h"
 #include "pbs_kernels.hip.h"
 #include "pbs_large_kernels.hip.h"
+#include "pbs_cluster_kernels.hip.h"
 #include "pbs_multibit_kernels.hip.h"
 #include "pbs_seq_kernels.hip.h"
 #include "seeded_kernels.hip.h"
@@ -64,6 +65,11 @@ struct BrVariant {
     // multi-bit on every other shape: two-kernel path only (generic combine + the classic kernel's EXTPROD mode)
     const void* extprod_fn = nullptr;
     const void* combine_generic_fn = nullptr;
+    // N >= 16384: several compute units of one XCD per LWE (pbs_cluster_kernels.hip.h); same Fourier key as rotate_fn
+    const void* cluster_fn = nullptr;
+    int cluster_size = 0;         // workgroups per LWE
+    size_t cluster_ws = 0;        // workspace bytes per cluster
+    size_t cluster_lds = 0;
 };
 
 template <int LOGN, int LOGR, int K1, int L>
@@ -106,6 +112,13 @@ BrVariant make_large_variant() {
     v.convert_ws = (size_t)CFG::P * 16;
     v.rotate_fn = reinterpret_cast<const void*>(&blind_rotate_large_kernel<LOGN, K1, L>);
     v.convert_fn = reinterpret_cast<const void*>(&bsk_convert_large_kernel<LOGN, K1, L>);
+    if constexpr (K1 == 2) {
+        using CC = BrClusterCfg<LOGN, K1, L>;
+        v.cluster_fn = reinterpret_cast<const void*>(&blind_rotate_cluster_kernel<LOGN, K1, L>);
+        v.cluster_size = CC::C;
+        v.cluster_ws = CC::WS_BYTES;
+        v.cluster_lds = CC::LDS_BYTES;
+    }
     return v;
 }
 
@@ -257,6 +270,7 @@ int Engine::create(const fhe_params_t& p, int device, Engine** out) {
     e->device = device;
     e->variant = v;
     e->variant_large = v;
+    if (const char* m = getenv("FHESTR_CLUSTER")) e->cluster_mode = std::min(1, std::max(-1, atoi(m)));
     if (const char* m = getenv("FHESTR_MULTIBIT_COMBINE_MAX")) e->multibit_combine_max = (uint32_t)std::min(1024, std::max(0, atoi(m)));
     if (env_logr == 0) {   // automatic: "wide" twin (same points per thread => same key layout) for big batches
         const BrVariant* w = find_variant(p, v->logR | 16);
@@ -277,7 +291,7 @@ Engine::~Engine() {
     if (stream) (void)hipStreamSynchronize(stream);
     auto rel = [](void* ptr) { if (ptr) (void)hipFree(ptr); };
     rel(d_ksk); rel(d_ksk_packed); rel(d_ksk_rowsum); rel(d_fbsk); rel(d_luts); rel(d_in); rel(d_small); rel(d_small2); rel(d_out); rel(d_idx);
-    rel(d_pool); rel(d_meta); rel(d_ws); rel(d_slot_exp);
+    rel(d_pool); rel(d_meta); rel(d_ws); rel(d_slot_exp); rel(d_cluster_ws); rel(d_cluster_ctl);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ring) if (e) (void)hipEventDestroy(e);
     for (auto& e : pipe_ev) if (e) (void)hipEventDestroy(e);
@@ -721,6 +735,29 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
         }
         return 0;
     }
+    if (v->cluster_fn && cluster_mode != 0 && (cluster_mode == 1 || count <= cluster_max_batch)) {
+        // Several CUs per LWE: the grid is a whole number of 8 * C workgroups (the dispatcher deals workgroups
+        // round-robin over the 8 XCDs, the kernel forms its clusters from what each XCD actually received),
+        // never more than one workgroup per CU -- every workgroup of the grid must be resident at once.
+        const uint32_t C = (uint32_t)v->cluster_size, quantum = 8 * C;
+        const uint32_t max_clusters = std::min<uint32_t>((uint32_t)CLUSTER_MAX, ((uint32_t)cu_count / quantum) * 8);
+        if (max_clusters == 0) return fail("cluster kernel: device has fewer than 8 * C compute units");
+        const uint32_t want = std::min(count, max_clusters);
+        const uint32_t grid = (want + 7) / 8 * quantum;
+        if (ensure(&d_cluster_ws, &cap_cluster_ws, (size_t)max_clusters * v->cluster_ws)) return 1;
+        if (!d_cluster_ctl) {
+            HIP_TRY(hipMalloc((void**)&d_cluster_ctl, sizeof(ClusterCtl) + sizeof(ClusterStatus)));
+            HIP_TRY(hipMemsetAsync(d_cluster_ctl, 0, sizeof(ClusterCtl) + sizeof(ClusterStatus), stream));
+        }
+        // tickets and flags start from zero; the status words behind them are sticky (read by cluster_status())
+        HIP_TRY(hipMemsetAsync(d_cluster_ctl, 0, sizeof(ClusterCtl), stream));
+        ClusterCtl* ctl = reinterpret_cast<ClusterCtl*>(d_cluster_ctl);
+        BlindRotateClusterArgs ka{a, reinterpret_cast<unsigned char*>(d_cluster_ws), ctl, reinterpret_cast<ClusterStatus*>(ctl + 1)};
+        void* kargs[] = {(void*)&ka};
+        HIP_TRY(hipLaunchKernel(v->cluster_fn, dim3(grid), dim3(v->threads), kargs, v->cluster_lds + (size_t)p.n * 4, stream));
+        cluster_unchecked = true;
+        return 0;
+    }
     if (v->large) {
         if (ensure(&d_ws, &cap_ws, (size_t)count * v->ws_bytes)) return 1;
         BlindRotateLargeArgs la{a, reinterpret_cast<unsigned char*>(d_ws)};
@@ -829,7 +866,7 @@ int Engine::ks_pbs_host(const uint64_t* in, const uint32_t* lut_idx, uint64_t* o
     if (ks_pbs_dev(d_in, lut_idx ? d_idx : nullptr, d_out, count)) return 1;
     HIP_TRY(hipMemcpyAsync(out, d_out, count * big * 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    return 0;
+    return cluster_check();
 }
 
 int Engine::keyswitch_host(const uint64_t* in, uint64_t* out_small, uint32_t count) {
@@ -855,7 +892,7 @@ int Engine::pbs_host(const uint64_t* in_small, const uint32_t* lut_idx, uint64_t
     if (launch_blind_rotate(d_small, lut_idx ? d_idx : nullptr, d_out, count)) return 1;
     HIP_TRY(hipMemcpyAsync(out, d_out, count * big * 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    return 0;
+    return cluster_check();
 }
 
 // Small-key order (programmable_bootstrap_keyswitch_assign, shortint/server_key/mod.rs:859-932):
@@ -873,7 +910,7 @@ int Engine::pbs_ks_host(const uint64_t* in_small, const uint32_t* lut_idx, uint6
     if (launch_keyswitch(d_out, d_small2, count)) return 1;
     HIP_TRY(hipMemcpyAsync(out_small, d_small2, count * small * 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    return 0;
+    return cluster_check();
 }
 
 int Engine::lincomb_dev(const uint64_t* d_pool_, const uint32_t* d_off, const uint32_t* d_src,
@@ -955,6 +992,22 @@ int Engine::synchronize() {
     if (use()) return 1;
     if (ks_stream) HIP_TRY(hipStreamSynchronize(ks_stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    return cluster_check();
+}
+
+// The cluster kernel never hangs on a hand-over that does not arrive: it gives up, finishes with garbage and says so
+// in its status words.  Every host-visible completion point asks here.
+int Engine::cluster_check() {
+    if (!cluster_unchecked || !d_cluster_ctl) return 0;
+    ClusterStatus st{};
+    HIP_TRY(hipMemcpy(&st, reinterpret_cast<ClusterCtl*>(d_cluster_ctl) + 1, sizeof(st), hipMemcpyDeviceToHost));
+    cluster_unchecked = false;
+    cluster_last = st.clusters;
+    if (st.error) {
+        HIP_TRY(hipMemset(reinterpret_cast<ClusterCtl*>(d_cluster_ctl) + 1, 0, sizeof(st)));
+        return fail("blind_rotate_cluster_kernel: a cluster hand-over timed out (code " + std::to_string(st.error) +
+                    "); results of that launch are invalid");
+    }
     return 0;
 }
 

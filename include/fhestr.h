@@ -94,6 +94,14 @@ int fhe_engine_set_pipeline(fhe_engine *eng, int on);
  * (env FHESTR_MULTIBIT_COMBINE_MAX); 0 = always fused.  Both paths give bit-identical ciphertexts.  Costs
  * max_batch * (n / grouping_factor) * (k+1)^2 * N * 8 bytes of device workspace when used. */
 int fhe_engine_set_multibit_combine_max(fhe_engine *eng, uint32_t max_batch);
+/* Polynomial sizes N >= 16384 (PARAM_MESSAGE_4_CARRY_4 ...): the blind rotation of one LWE is spread over a
+ * cluster of compute units of one XCD (8 for N = 32768, 4 for N = 16384) that exchange the four-step transform's
+ * matrices through that XCD's L2.  mode: -1 automatic (default; env FHESTR_CLUSTER), 0 never (one workgroup per
+ * LWE through an HBM workspace), 1 always; max_batch: in automatic mode, batches above it take the one-workgroup
+ * kernel.  Both kernels read the same Fourier key and give decrypt-identical results. */
+int fhe_engine_set_cluster_mode(fhe_engine *eng, int mode, uint32_t max_batch);
+/* After a synchronisation: clusters the last cluster launch formed (0 if none ran). */
+int fhe_engine_cluster_info(fhe_engine *eng, uint32_t *clusters);
 
 /* ---- lookup tables ------------------------------------------------------------------------- */
 /* generate_lookup_table (shortint/server_key/mod.rs:383-399, engine/mod.rs:72-128):

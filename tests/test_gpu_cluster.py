@@ -1,0 +1,92 @@
+"""GPU parity of blind_rotate_cluster_kernel (csrc/pbs_cluster_kernels.hip.h): several compute units of one XCD
+per LWE for N >= 16384, against the CPU oracle and against the one-workgroup-per-LWE kernel on the same keys.
+
+Reference path: fft64/crypto/bootstrap.rs:242-364, ggsw.rs:477-598; parameters shortint/parameters/mod.rs:1063-1077
+(N = 32768) and the N = 16384 family.  Bit-exact where the path is integer-only (zero-mask PBS: rotation, sample
+extraction), decrypt-exact and within the noise model's 8 sigma of the oracle's f64 path otherwise."""
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import gpu_engine, keyset, torus_distance, to_fhestr_params
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [O.TOY_N32768] + [p for p in O.TOY_SHAPES if p.N >= 16384]
+
+
+def _phases(ks, cts):
+    return np.array([ks.ck.decrypt_plaintext(c) for c in cts], dtype=np.uint64)
+
+
+def _tolerance(p):
+    import fhestr
+    v_pbs = fhestr.noise_model(to_fhestr_params(p))["v_pbs"]
+    return 8.0 * np.sqrt(2.0 * v_pbs) * 2.0**64
+
+
+@pytest.mark.parametrize("params", SHAPES, ids=lambda p: p.name)
+def test_cluster_kernel_against_oracle(params):
+    ks = keyset(params)
+    eng = gpu_engine(ks)
+    M = params.msg_mod * params.carry_mod
+    f = lambda x: (3 * x + 1) % M
+    lut, _ = ks.sk.generate_lookup_table(f)
+    lut_id = eng.upload_lut(lut)
+    eng.set_cluster_mode(1)
+    try:
+        # zero-mask PBS (no CMUX step runs: LUT rotation, hand-over of the published accumulator, sample extraction)
+        small = np.zeros((4, params.small_size), dtype=np.uint64)
+        small[:, -1] = np.array([0, 2**64 - 1, 2**63, 0x0123456789ABCDEF], dtype=np.uint64)
+        idx = np.full(4, lut_id, dtype=np.uint32)
+        assert np.array_equal(eng.pbs(small, idx), np.stack([ks.sk.pbs(s, lut) for s in small]))
+        clusters = eng.cluster_info()
+        print(f"{params.name}: {clusters} clusters formed")
+        assert clusters >= 1
+        # full KS + PBS: decrypt-exact, phase within 8 sigma of the oracle's f64 path
+        msgs = np.array([0, 1, M // 2, M - 1, 5, 7])
+        enc = ks.ck.encrypt_many(msgs, O.Rng(99, 3))
+        got = eng.apply_lookup_table(enc, np.full(len(msgs), lut_id, dtype=np.uint32))
+        assert np.array_equal(ks.ck.decrypt_many(got), np.array([f(int(m)) for m in msgs]))
+        want = ks.sk.apply_lookup_table_batch(enc, lut)
+        dist = torus_distance(_phases(ks, got), _phases(ks, want))
+        tol = _tolerance(params)
+        print(f"{params.name}: max phase distance cluster kernel vs oracle = 2^{np.log2(dist.max() + 1):.1f} (8 sigma = 2^{np.log2(tol):.1f})")
+        assert dist.max() < tol
+        # the one-workgroup-per-LWE kernel on the same inputs: same messages, phases as close
+        eng.set_cluster_mode(0)
+        ref = eng.apply_lookup_table(enc, np.full(len(msgs), lut_id, dtype=np.uint32))
+        assert np.array_equal(ks.ck.decrypt_many(ref), ks.ck.decrypt_many(got))
+        assert torus_distance(_phases(ks, got), _phases(ks, ref)).max() < tol
+    finally:
+        eng.set_cluster_mode(-1)
+
+
+@pytest.mark.parametrize("params", [O.TOY_N32768, [p for p in O.TOY_SHAPES if p.N == 16384][0]], ids=lambda p: p.name)
+def test_cluster_kernel_more_lwes_than_clusters(params):
+    """Every cluster walks several LWEs (epoch flags, workspace and mask table reused), ragged count, two tables."""
+    ks = keyset(params)
+    eng = gpu_engine(ks)
+    M = params.msg_mod * params.carry_mod
+    fs = [lambda x: (3 * x + 1) % M, lambda x: (M - 1 - x)]
+    ids = [eng.upload_lut(ks.sk.generate_lookup_table(f)[0]) for f in fs]
+    eng.set_cluster_mode(1)
+    try:
+        B = 2 * 64 + 3
+        rng = np.random.default_rng(17)
+        msgs = rng.integers(0, M, size=B)
+        which = rng.integers(0, 2, size=B)
+        enc = ks.ck.encrypt_many(msgs, O.Rng(123, 4))
+        got = eng.apply_lookup_table(enc, np.array([ids[w] for w in which], dtype=np.uint32))
+        want = np.array([fs[w](int(m)) for m, w in zip(msgs, which)])
+        assert np.array_equal(ks.ck.decrypt_many(got), want)
+        # a_i == 0 is skipped by the whole cluster (bootstrap.rs:281): zero out some mask elements after the keyswitch
+        small = eng.keyswitch(enc[:5])
+        small[:, 1] = 0
+        idx = np.full(5, ids[0], dtype=np.uint32)
+        a = eng.pbs(small, idx)
+        eng.set_cluster_mode(0)
+        b = eng.pbs(small, idx)
+        assert np.array_equal(ks.ck.decrypt_many(a), ks.ck.decrypt_many(b))
+    finally:
+        eng.set_cluster_mode(-1)
