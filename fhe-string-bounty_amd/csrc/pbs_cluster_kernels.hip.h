@@ -27,6 +27,13 @@
 #pragma once
 #include "pbs_large_kernels.hip.h"
 
+#define FHESTR_CL_KEY_AUX 0       // Fourier-key loads: default policy (shared by the clusters of an XCD through L2)
+
+// cache policy of the loads of exchanged data: sc1 = past the vector L1, served by the XCD's L2.  (Measured and dropped:
+// sc1 | nt on these loads, nt on the key loads, and starting half of an XCD's clusters half a step late -- all within
+// -4 % .. 0 % at 32 clusters, same L2 miss counts)
+#define FHESTR_CL_XCHG_AUX 16
+
 namespace fhe {
 
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
@@ -67,7 +74,17 @@ struct BrClusterCfg {
     static constexpr size_t WS_T = (size_t)U * P1 * PITCH * 16;     // T[u][row'][col] c64
     static constexpr size_t WS_ACC = (size_t)K1 * N * 8;            // published accumulator [p][col][2*P1] u64
     static constexpr size_t WS_BYTES = WS_T + WS_ACC;               // per cluster
-    static constexpr size_t LDS_BYTES = LC::LDS_BYTES;              // + 4 n: modulus-switched mask
+    // LDS: exchange planes (all real planes, then all imaginary ones: too far apart for hipcc to fuse a re/im pair
+    // into ds_read2_b64, half the LDS rate of two plain reads), per-thread constant tables, FFT twiddles, mask
+    static constexpr int SLOTS_A = P1 + 16, SLOTS_B = P2 + 16;     // neighbouring transforms 16 slots apart mod 32
+    static constexpr int IM_A = GROUPS_A * SLOTS_A + 2, IM_B = GROUPS_B * SLOTS_B + 2;   // not a multiple of 64 slots (ds_read2st64_b64)
+    static constexpr size_t LDS_PLANES = (size_t)8 * (IM_A > IM_B ? 2 * IM_A : 2 * IM_B);
+    static constexpr size_t LDS_E1 = (size_t)P1 * 16;               // e^{i pi a P2 / N}: twist, row part
+    static constexpr size_t LDS_TW2 = (size_t)COLS * P1 * 16;       // [column][rho][tau]: four-step twiddle * column part of the twist
+    static constexpr size_t LDS_TW3 = (size_t)ROWS * P2 * 16;       // [row][m][tau]: conjugate twiddle * conjugate column twist
+    static constexpr size_t LDS_TWA = (size_t)FftTwiddleTable<PA>::ENTRIES * 16, LDS_TWB = (size_t)FftTwiddleTable<PB>::ENTRIES * 16;
+    static constexpr size_t LDS_BYTES = LDS_PLANES + LDS_E1 + LDS_TW2 + LDS_TW3 + LDS_TWA + LDS_TWB;   // + 4 n: modulus-switched mask
+    static_assert(LDS_BYTES + 4 * 1280 <= 160 * 1024, "LDS budget");
     // T rows are stored permuted: the 16 rows a thread group writes with one store instruction (fixed register
     // slot rho, A = slot_addr(tau, rho) = 8 tau + rho) are neighbours, and a workgroup's ROWS rows are one block
     __host__ __device__ static constexpr int row_perm(int A) { return ((A & 7) << (LOGP1 - 3)) | (A >> 3); }
@@ -83,24 +100,28 @@ struct BlindRotateClusterArgs {
 
 template <class RSRC>
 __device__ __forceinline__ double2 load_sc1_b128(RSRC rsrc, uint32_t voff) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 16 /* sc1: past the L1, served by L2 */);
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, FHESTR_CL_XCHG_AUX);
     double2 d;
     __builtin_memcpy(&d, &v, 16);
     return d;
 }
 template <class RSRC>
 __device__ __forceinline__ uint64_t load_sc1_b64(RSRC rsrc, uint32_t voff) {
-    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, 0, 16);
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, 0, FHESTR_CL_XCHG_AUX);
     return ((uint64_t)v.y << 32) | v.x;
 }
 
 // All C workgroups of the cluster have stored what the next phase reads.  A wait that does not end within
 // CLUSTER_SPIN_LIMIT polls marks the launch dead (LDS word + ctl->error + the sticky status): every later wait of
 // every cluster returns at once, the kernel drains with garbage and the host reports it (Engine::cluster_check).
-template <int C>
-__device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, uint32_t& epoch, volatile uint32_t* s_dead,
+// PREFETCHED: vector-memory loads the caller issued AFTER its last store and wants to keep in flight across the
+// hand-over (vmcnt counts loads and stores together, in issue order: all but the youngest PREFETCHED are done).
+template <int C, int PREFETCHED = 0>
+__device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, uint32_t& epoch, uint32_t* s_dead_generic,
                                              ClusterCtl* ctl, ClusterStatus* status) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have reached L2
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32_t;     // a plain LDS access (a generic pointer would be a
+    lds_vu32_t* s_dead = (lds_vu32_t*)(uintptr_t)lds_address(s_dead_generic);   // flat load: it waits for vmcnt(0) as well)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PREFETCHED) : "memory");      // this wave's stores have reached L2
     __syncthreads();
     ++epoch;
     if (threadIdx.x < 64 && !*s_dead) {
@@ -130,7 +151,6 @@ template <int LOGN, int K1, int L>
 __global__ void __launch_bounds__((BrClusterCfg<LOGN, K1, L>::THREADS))
 blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
     using CFG = BrClusterCfg<LOGN, K1, L>;
-    using LC = typename CFG::LC;
     using PA = typename CFG::PA;
     using PB = typename CFG::PB;
     constexpr int N = CFG::N, P = CFG::P, P1 = CFG::P1, P2 = CFG::P2, R = CFG::R, NT = CFG::THREADS;
@@ -184,41 +204,81 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
     // ---- thread roles ----
     // phases 1 and 3: group (p, bl) of TA threads owns column b = member * COLS + bl of polynomial p
     const int gA = tid / TA, tauA = tid % TA;
-    const int pA = gA / CFG::COLS, b = (int)member * CFG::COLS + gA % CFG::COLS;
+    const int pA = gA / CFG::COLS, blA = gA % CFG::COLS, b = (int)member * CFG::COLS + blA;
     // phase 2: groups 2 rl + h of TB threads own row A' = member * ROWS + rl; half h takes UH digit polynomials
     const int gB = tid / TB, tauB = tid % TB;
-    const int hB = gB & 1, rowp = (int)member * CFG::ROWS + (gB >> 1);
+    const int hB = gB & 1, rlB = gB >> 1, rowp = (int)member * CFG::ROWS + rlB;
     const int rowA = CFG::row_unperm(rowp);
-    double* areA = lds + (size_t)gA * LC::SLOTS_A;
-    double* aimA = areA + P1 + 2;
-    double* breB = lds + (size_t)gB * LC::SLOTS_B;
-    double* bimB = breB + P2 + 2;
-    double* preB = lds + (size_t)(gB ^ 1) * LC::SLOTS_B;       // the partner group's planes
-    double* pimB = preB + P2 + 2;
+    constexpr int IM_A = CFG::IM_A, IM_B = CFG::IM_B;
+    double* areA = lds + (size_t)gA * CFG::SLOTS_A;
+    double* aimA = areA + IM_A;
+    double* breB = lds + (size_t)gB * CFG::SLOTS_B;
+    double* bimB = breB + IM_B;
+    double* preB = lds + (size_t)(gB ^ 1) * CFG::SLOTS_B;       // the partner group's planes
+    double* pimB = preB + IM_B;
 
-    double2* twa = reinterpret_cast<double2*>(smem + LC::LDS_PLANES + LC::LDS_ROOTS);
+    double2* e1 = reinterpret_cast<double2*>(smem + CFG::LDS_PLANES);
+    double2* tw2 = e1 + P1;
+    double2* tw3 = tw2 + CFG::COLS * P1;
+    double2* twa = tw3 + CFG::ROWS * P2;
     double2* twb = twa + FftTwiddleTable<PA>::ENTRIES;
+    uint32_t* lds_d = reinterpret_cast<uint32_t*>(smem + CFG::LDS_BYTES);     // [n] modulus-switched mask
     FftTwiddleTable<PA>::fill(twa, tid, NT);
     FftTwiddleTable<PB>::fill(twb, tid, NT);
     const FftTwiddleTable<PA> fca{twa, tauA};
     const FftTwiddleTable<PB> fcb{twb, tauB};
-    RootTable<LC> roots;
-    roots.init(reinterpret_cast<double2*>(smem + LC::LDS_PLANES), tid, NT);
-    uint32_t* lds_d = reinterpret_cast<uint32_t*>(smem + LC::LDS_BYTES);     // [n] modulus-switched mask
+    // Constant factors of this workgroup's columns and rows, one 16-byte LDS read each in the loop.  With the
+    // twist e^{i pi j / N}, j = a P2 + b, split into a row part E1[a] and a column part E2[b] = e^{i pi b / N}, the
+    // column part commutes with the column transforms and is folded into the four-step twiddles on either side:
+    //   tw2[bl][rho][tau] = e^{-2 pi i q1(8 tau + rho) b / P} * E2[b]          (after the forward column transform)
+    //   tw3[rl][m][tau]   = e^{+2 pi i q1(row) bb / P} * conj(E2[bb]), bb = tau + TB m   (after the inverse row transform)
+    // Angles as integers mod 2N (units of pi / N), so sincospi sees an exact argument.
+    for (int e = tid; e < P1; e += NT) {
+        double sn, cs;
+        sincospi((double)((uint32_t)e * P2) / (double)N, &sn, &cs);
+        e1[e] = make_double2(cs, sn);
+    }
+    for (int e = tid; e < CFG::COLS * P1; e += NT) {
+        const int bl = e / P1, rho = (e / TA) % R, tau = e % TA;
+        const uint32_t bb = member * CFG::COLS + bl;
+        const uint32_t q1 = (uint32_t)freq_of_addr<PA>(slot_addr<PA>(tau, rho));
+        const uint32_t ang = (bb - 4u * q1 * bb) & (2u * N - 1u);
+        double sn, cs;
+        sincospi((double)ang / (double)N, &sn, &cs);
+        tw2[e] = make_double2(cs, sn);
+    }
+    for (int e = tid; e < CFG::ROWS * P2; e += NT) {
+        const int rl = e / P2, bb = (e % P2) / TB * TB + e % TB;      // [rl][m][tau] with bb = tau + TB m: e % P2 = m TB + tau
+        const uint32_t q1 = (uint32_t)freq_of_addr<PA>(CFG::row_unperm((int)member * CFG::ROWS + rl));
+        const uint32_t ang = (4u * q1 * (uint32_t)bb - (uint32_t)bb) & (2u * N - 1u);
+        double sn, cs;
+        sincospi((double)ang / (double)N, &sn, &cs);
+        tw3[e] = make_double2(cs, sn);
+    }
+    const double2* my_e1 = e1 + tauA;                               // + TA m
+    const double2* my_tw2 = tw2 + (size_t)blA * P1 + tauA;          // + TA rho
+    const double2* my_tw3 = tw3 + (size_t)rlB * P2 + tauB;          // + TB m
 
     unsigned char* ws = ca.workspace + (size_t)cluster * CFG::WS_BYTES;
-    double2* Tm = reinterpret_cast<double2*>(ws);                              // [U][P1][PITCH]
-    uint64_t* accpub = reinterpret_cast<uint64_t*>(ws + CFG::WS_T);           // [K1][P2][2*P1]
     const auto t_rsrc = __builtin_amdgcn_make_buffer_rsrc(ws, 0, (int)CFG::WS_T, 0x00020000);
     const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(ws + CFG::WS_T, 0, (int)CFG::WS_ACC, 0x00020000);
+    // byte offsets of this thread inside the cluster's matrices; the rest of every address is a compile-time constant
+    const uint32_t voff_t1 = (uint32_t)(((pA * P1 + tauA) * PITCH + b) * 16);              // phase 1 store: + (it K1 P1 + 16 rho) PITCH
+    const uint32_t voff_t2 = (uint32_t)((((hB * UH) * P1 + rowp) * PITCH + tauB) * 16);    // phase 2: + (uu P1 PITCH + TB m)
+    const uint32_t voff_t3 = (uint32_t)((((pA * UH) * P1 + tauA) * PITCH + b) * 16);       // phase 3 load: + 16 rho PITCH
+    const uint32_t voff_pub = (uint32_t)(((pA * P2 + b) * (2 * P1) + tauA) * 8);           // publish: + (h P1 + TA m)
+    uint32_t voff_key[UH];       // GGSW rows of this half's digit polynomials: + (col P + rho TB)
+#pragma unroll
+    for (int uu = 0; uu < UH; uu++) {
+        const int u = hB * UH + uu, it = u / K1, row = u % K1;
+        voff_key[uu] = (uint32_t)(((((L - 1 - it) * K1 + row) * K1) * P + rowA * P2 + tauB) * 16);
+    }
     uint32_t* flags = &ctl->flags[cluster][0][0];
     uint32_t epoch = 0;
 
     const uint32_t n = args.n;
     const uint32_t bL = args.base_log * L;
-    const double2* fbsk = reinterpret_cast<const double2*>(args.fbsk);
-    constexpr size_t GGSW_ELEMS = (size_t)L * K1 * K1 * P;
-    const int q1row = freq_of_addr<PA>(rowA);
+    constexpr size_t GGSW_BYTES = (size_t)L * K1 * K1 * P * 16;
 
     for (uint32_t sample = cluster; sample < args.batch; sample += n_clusters) {
         const uint64_t* lwe = args.lwe_small + (size_t)sample * (n + 1);
@@ -244,7 +304,9 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
                     const bool neg = ((j + rem) >= (uint32_t)N) != odd;
                     const uint64_t v = lut[(size_t)pA * N + src];
                     own[2 * m + h] = neg ? (0 - v) : v;
-                    accpub[((size_t)pA * P2 + b) * (2 * P1) + h * P1 + tauA + TA * m] = own[2 * m + h];
+                    const uint64_t o = own[2 * m + h];
+                    u32x2_t w; w.x = (uint32_t)o; w.y = (uint32_t)(o >> 32);
+                    __builtin_amdgcn_raw_buffer_store_b64(w, a_rsrc, (int)voff_pub, (h * P1 + TA * m) * 8, 0);
                 }
             }
         }
@@ -255,94 +317,101 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t d = lds_d[i];
             if (d == 0xFFFFFFFFu) continue;       // a_i == 0 (bootstrap.rs:281): the same for the whole cluster
-            const uint32_t rem = d & (N - 1);
-            const bool odd = (d >> LOGN) & 1;
 
             // ---- phase 1: rotate, subtract, decompose, twist, column transforms, twiddle -> T ----
             {
                 using state_t = typename std::conditional<(L >= 3), uint64_t, uint32_t>::type;
                 state_t st_lo[R], st_hi[R];
-                const uint32_t bsrc = ((uint32_t)b - rem) & (P2 - 1);
-                const uint32_t colbase = ((uint32_t)pA * P2 + bsrc) * (2 * P1);
-                uint64_t rot[2 * R];
+                // coefficient j = e P2 + b with e = h P1 + a; rem = rq P2 + rb: (j - rem) mod N sits in column
+                // (b - rb) mod P2 at e' = (e - rq - [b < rb]) mod 2 P1, negated iff that difference wrapped (xor odd)
+                const uint32_t rem = d & (N - 1);
+                const int32_t oddmask = -(int32_t)((d >> LOGN) & 1);
+                const uint32_t rb = rem & (P2 - 1);
+                const int32_t shift = (int32_t)tauA - (int32_t)(rem >> LOGP2) - ((uint32_t)b < rb ? 1 : 0);
+                const uint32_t colbase8 = ((uint32_t)pA * P2 + (((uint32_t)b - rb) & (P2 - 1))) * (2 * P1) * 8;
 #pragma unroll
                 for (int m = 0; m < R; m++) {
+                    uint64_t ct[2];
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
-                        const uint32_t j = (uint32_t)h * P + (uint32_t)(tauA + TA * m) * P2 + (uint32_t)b;
-                        const uint32_t e = ((j - rem) & (N - 1)) >> LOGP2;
-                        rot[2 * m + h] = load_sc1_b64(a_rsrc, (colbase + e) * 8);
+                        const int32_t e = shift + (h * P1 + TA * m);
+                        const uint32_t voff = (((uint32_t)e << 3) & ((2u * P1 - 1u) << 3)) | colbase8;
+                        const uint64_t v = load_sc1_b64(a_rsrc, voff);
+                        const uint64_t msk = (uint64_t)(int64_t)((e >> 31) ^ oddmask);
+                        ct[h] = ((v ^ msk) - msk) - own[2 * m + h];
                     }
-                }
-#pragma unroll
-                for (int m = 0; m < R; m++) {
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const uint32_t j = (uint32_t)h * P + (uint32_t)(tauA + TA * m) * P2 + (uint32_t)b;
-                        const bool neg = (j < rem) != odd;
-                        uint64_t v = rot[2 * m + h];
-                        v = neg ? (0 - v) : v;
-                        const uint64_t ct1 = v - own[2 * m + h];
-                        state_t st;
-                        if constexpr (L >= 3) st = decomp_init_state64(ct1, bL);
-                        else st = decomp_init_state(ct1, bL);
-                        if (h == 0) st_lo[m] = st; else st_hi[m] = st;
-                    }
+                    if constexpr (L >= 3) { st_lo[m] = decomp_init_state64(ct[0], bL); st_hi[m] = decomp_init_state64(ct[1], bL); }
+                    else { st_lo[m] = decomp_init_state(ct[0], bL); st_hi[m] = decomp_init_state(ct[1], bL); }
                 }
 #pragma unroll
                 for (int it = 0; it < L; it++) {
                     cplx x[R];
 #pragma unroll
                     for (int m = 0; m < R; m++) {
-                        const int j = (tauA + TA * m) * P2 + b;
-                        cplx z;
+                        double zr, zi;
                         if constexpr (L >= 3) {
-                            z.re = (double)decomp_next_digit64(st_lo[m], args.base_log);
-                            z.im = (double)decomp_next_digit64(st_hi[m], args.base_log);
+                            zr = (double)decomp_next_digit64(st_lo[m], args.base_log);
+                            zi = (double)decomp_next_digit64(st_hi[m], args.base_log);
                         } else {
-                            z.re = (double)decomp_next_digit(st_lo[m], args.base_log);
-                            z.im = (double)decomp_next_digit(st_hi[m], args.base_log);
+                            zr = (double)decomp_next_digit(st_lo[m], args.base_log);
+                            zi = (double)decomp_next_digit(st_hi[m], args.base_log);
                         }
-                        x[m] = cmul(z, roots.get((uint32_t)j));
+                        const double2 w = my_e1[TA * m];
+                        x[m].re = zr * w.x - zi * w.y;
+                        x[m].im = zr * w.y + zi * w.x;
                     }
                     fft_forward<PA>(x, fca, areA, aimA, tauA);
-                    double2* dst = Tm + (size_t)(it * K1 + pA) * P1 * PITCH;
 #pragma unroll
                     for (int rho = 0; rho < R; rho++) {
-                        const int A = slot_addr<PA>(tauA, rho);
-                        const int q1 = freq_of_addr<PA>(A);
-                        const cplx w = roots.get(0u - 4u * (uint32_t)(q1 * b));     // e^{-2 pi i q1 b / P}
-                        const cplx v = cmul(x[rho], w);
-                        dst[(size_t)CFG::row_perm(A) * PITCH + b] = make_double2(v.re, v.im);
+                        const double2 w = my_tw2[TA * rho];
+                        double2 v;
+                        v.x = x[rho].re * w.x - x[rho].im * w.y;
+                        v.y = x[rho].re * w.y + x[rho].im * w.x;
+                        u32x4_t raw;
+                        __builtin_memcpy(&raw, &v, 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(raw, t_rsrc, (int)voff_t1, ((it * K1 * P1 + 16 * rho) * PITCH) * 16, 0);
                     }
                 }
             }
             FHE_STAMP(1);
-            cluster_sync<C>(flags, member, epoch, &s_dead, ctl, ca.status);
+            // the GGSW rows of this half's first digit polynomial do not depend on the hand-over: request them now
+            const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(args.fbsk)) + (size_t)i * GGSW_BYTES, 0, (int)GGSW_BYTES, 0x00020000);
+            double2 bv[K1][R];
+            auto issue_key = [&](int uu) {
+#pragma unroll
+                for (int col = 0; col < K1; col++) {
+#pragma unroll
+                    for (int rho = 0; rho < R; rho++) {
+                        const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, (int)voff_key[uu], (col * P + rho * TB) * 16, FHESTR_CL_KEY_AUX);
+                        __builtin_memcpy(&bv[col][rho], &raw, 16);
+                    }
+                }
+            };
+            asm volatile("" ::: "memory");         // after the phase's stores in issue order
+            issue_key(0);
+            asm volatile("" ::: "memory");
+            cluster_sync<C, K1 * R>(flags, member, epoch, &s_dead, ctl, ca.status);
             FHE_STAMP(2);
 
             // ---- phase 2: row transforms, multiply-accumulate with the GGSW, inverse row transforms, in place ----
             {
-                const double2* bk0 = fbsk + (size_t)i * GGSW_ELEMS;
                 cplx outf[K1][R];
-#pragma unroll
-                for (int uu = 0; uu < UH; uu++) {
-                    const int u = hB * UH + uu;            // u = it * K1 + row (ggsw.rs:524 order within a half)
-                    const int it = u / K1, row = u % K1;
-                    const int lvl_idx = L - 1 - it;
-                    cplx x[R];
+                double2 xin[R];
+                auto issue_row = [&](int uu) {
 #pragma unroll
                     for (int m = 0; m < R; m++) {
-                        const double2 v = load_sc1_b128(t_rsrc, (uint32_t)(((u * P1 + rowp) * PITCH + tauB + TB * m) * 16));
-                        x[m].re = v.x; x[m].im = v.y;
+                        const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(t_rsrc, (int)voff_t2, (uu * P1 * PITCH + TB * m) * 16, FHESTR_CL_XCHG_AUX);
+                        __builtin_memcpy(&xin[m], &raw, 16);
                     }
-                    double2 bv[K1][R];
+                };
+                issue_row(0);
 #pragma unroll
-                    for (int col = 0; col < K1; col++) {
-                        const double2* bk = bk0 + (((size_t)lvl_idx * K1 + row) * K1 + col) * P + (size_t)rowA * P2;
+                for (int uu = 0; uu < UH; uu++) {
+                    cplx x[R];
 #pragma unroll
-                        for (int rho = 0; rho < R; rho++) bv[col][rho] = bk[rho * TB + tauB];
-                    }
+                    for (int m = 0; m < R; m++) { x[m].re = xin[m].x; x[m].im = xin[m].y; }
+                    if (uu + 1 < UH) issue_row(uu + 1);
                     fft_forward<PB>(x, fcb, breB, bimB, tauB);
 #pragma unroll
                     for (int col = 0; col < K1; col++) {
@@ -358,6 +427,7 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
                             }
                         }
                     }
+                    if (uu + 1 < UH) issue_key(uu + 1);
                 }
                 // the halves swap the partial sum of the column the OTHER one finishes (same wavefront: LDS in order)
                 wave_local_fence();
@@ -377,13 +447,15 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
                 }
                 wave_local_fence();
                 fft_inverse<PB>(mine, fcb, breB, bimB, tauB);
-                double2* dpoly = Tm + ((size_t)(hB * UH) * P1 + rowp) * PITCH;
 #pragma unroll
                 for (int m = 0; m < R; m++) {
-                    const int bb = tauB + TB * m;
-                    const cplx w = roots.get(4u * (uint32_t)(q1row * bb));   // conj of the forward twiddle
-                    const cplx v = cmul(mine[m], w);
-                    dpoly[bb] = make_double2(v.re, v.im);
+                    const double2 w = my_tw3[TB * m];
+                    double2 v;
+                    v.x = mine[m].re * w.x - mine[m].im * w.y;
+                    v.y = mine[m].re * w.y + mine[m].im * w.x;
+                    u32x4_t raw;
+                    __builtin_memcpy(&raw, &v, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(raw, t_rsrc, (int)voff_t2, (TB * m) * 16, 0);
                 }
             }
             FHE_STAMP(3);
@@ -395,20 +467,25 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
                 cplx x[R];
 #pragma unroll
                 for (int rho = 0; rho < R; rho++) {
-                    const int A = slot_addr<PA>(tauA, rho);
-                    const double2 v = load_sc1_b128(t_rsrc, (uint32_t)((((pA * UH) * P1 + CFG::row_perm(A)) * PITCH + b) * 16));
+                    const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(t_rsrc, (int)voff_t3, (16 * rho * PITCH) * 16, FHESTR_CL_XCHG_AUX);
+                    double2 v;
+                    __builtin_memcpy(&v, &raw, 16);
                     x[rho].re = v.x; x[rho].im = v.y;
                 }
                 fft_inverse<PA>(x, fca, areA, aimA, tauA);
-                uint64_t* pub = accpub + ((size_t)pA * P2 + b) * (2 * P1);
 #pragma unroll
                 for (int m = 0; m < R; m++) {
-                    const int j = (tauA + TA * m) * P2 + b;
-                    const cplx t = cmul_conj(x[m], roots.get((uint32_t)j));
-                    own[2 * m] += from_torus(t.re);
-                    own[2 * m + 1] += from_torus(t.im);
-                    pub[tauA + TA * m] = own[2 * m];
-                    pub[P1 + tauA + TA * m] = own[2 * m + 1];
+                    const double2 w = my_e1[TA * m];
+                    const double tre = x[m].re * w.x + x[m].im * w.y;      // * conj(E1[a])
+                    const double tim = x[m].im * w.x - x[m].re * w.y;
+                    own[2 * m] += from_torus(tre);
+                    own[2 * m + 1] += from_torus(tim);
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const uint64_t o = own[2 * m + h];
+                        u32x2_t w2; w2.x = (uint32_t)o; w2.y = (uint32_t)(o >> 32);
+                        __builtin_amdgcn_raw_buffer_store_b64(w2, a_rsrc, (int)voff_pub, (h * P1 + TA * m) * 8, 0);
+                    }
                 }
             }
             FHE_STAMP(5);

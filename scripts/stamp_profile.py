@@ -22,10 +22,17 @@ if len(sys.argv) > 2 and sys.argv[2] == "p44":      # the large-N kernel: phases
     P = fhestr.PARAM_MESSAGE_4_CARRY_4_KS_PBS
     SEGS = ["step head", "phase 1: decompose + column transforms -> tmp", "barrier 1", "phase 2: rows, multiply-accumulate, inverse rows -> tmp2",
             "barrier 2", "phase 3: inverse columns, accumulate", "barrier 3", "-", "-", "-"]
+CLUSTER = len(sys.argv) > 2 and sys.argv[2] == "p44c"
+if CLUSTER:                                          # the cluster kernel (several CUs per LWE): same phases, cluster hand-overs
+    P = fhestr.PARAM_MESSAGE_4_CARRY_4_KS_PBS
+    SEGS = ["-", "phase 1: gather, decompose, column transforms -> T", "hand-over 1", "phase 2: rows, multiply-accumulate, inverse rows",
+            "hand-over 2", "phase 3: inverse columns, accumulate, publish", "hand-over 3", "-", "-", "-"]
 ck = fhestr.ClientKey(P, 7)
 g, s = ck.secret_keys()
 eng = fhestr.Engine(P, 0)
 eng.generate_keys(g, s, 7)
+if CLUSTER:
+    eng.set_cluster_mode(1)
 lut, _ = eng.generate_lookup_table(lambda x: x)
 rng = np.random.default_rng(0)
 msgs = rng.integers(0, P.msg_mod * P.carry_mod, size=B)
@@ -33,12 +40,16 @@ cts = ck.encrypt(msgs)
 for _ in range(1 if P.N > 4096 else 3):
     out = eng.apply_lookup_table(cts, np.full(B, lut, dtype=np.uint32))
 print("correct:", np.array_equal(ck.decrypt(out), msgs), "kernel ms", eng.last_kernel_ms())
-n = B * 8 * len(SEGS)
+NB = 256 if CLUSTER else B          # the cluster kernel stamps per workgroup of its grid (first LWE of every cluster)
+n = NB * 8 * len(SEGS)
 buf = np.zeros(n, dtype=np.uint64)
 L = fhestr.lib()
 L.fhe_debug_read_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert L.fhe_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), n) == 0
-st = buf.reshape(B, 8, len(SEGS)).astype(np.float64) / P.n     # cycles per step (s_memtime: shader clock... 100 MHz ticks?)
+st = buf.reshape(NB, 8, len(SEGS)).astype(np.float64) / P.n
+if CLUSTER:
+    st = st[st.sum(axis=(1, 2)) > 0]
+    print(f"{st.shape[0]} workgroups stamped")     # cycles per step (s_memtime: shader clock... 100 MHz ticks?)
 tot = st.sum(axis=2).mean()
 print(f"sum of segments: {tot:.0f} ticks per step and wave")
 for i, name in enumerate(SEGS):
