@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-leve
 # FP64 vector peak: 256 CUs x 4 SIMDs x 16 f64 FMA lanes/clk x 2 FLOP x 2.4 GHz = half the guide's
 # 157.3 TF FP32 vector rate (one wave64 f64 instruction occupies its SIMD for >= 4 cycles)
 F64_VALU_PEAK_TFLOPS = 78.6
-COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")   # written by scripts/collect_counters.py
+COUNTERS = os.path.join(ROOT, "profiles", "r03_counters.json")   # written by scripts/prof_round.py (round 3 kernels)
 SEED = 0x5EED0002
 
 
@@ -55,7 +55,11 @@ def cpu_baseline(P, bsk, ksk, cts, lut_tables, lut_sel):
     import oracle as O
     op = O.Params(P.n, P.k, P.N, P.pbs_base_log, P.pbs_level, P.ks_base_log, P.ks_level,
                   P.msg_mod, P.carry_mod, P.lwe_std, P.glwe_std, P.name)
-    cores = min(os.cpu_count() or 1, 16)
+    # all host threads (the reference's throughput bench does the same, benches/core_crypto/pbs_bench.rs:517-532);
+    # the sample is the batch tiled up to two LWEs per thread, so every thread has work for the whole measurement
+    cores = os.cpu_count() or 1
+    if os.environ.get("FHESTR_CPU_BASELINE_THREADS"):
+        cores = max(1, int(os.environ["FHESTR_CPU_BASELINE_THREADS"]))
     try:   # rebuild the checker for this host's ISA (AVX-512 where present); falls back to the shipped build
         O.build(force=True, arch="native")
     except Exception:
@@ -66,12 +70,21 @@ def cpu_baseline(P, bsk, ksk, cts, lut_tables, lut_sel):
     luts = np.zeros((len(lut_tables), op.glwe_len), dtype=np.uint64)
     for i, t in enumerate(lut_tables):
         L.orc_fill_accumulator(C.byref(op.c()), np.ascontiguousarray(t, dtype=np.uint64), luts[i])
-    out = np.zeros_like(cts)
-    idx = np.ascontiguousarray(lut_sel, dtype=np.uint32)
+    n_batch = cts.shape[0]
+    tiles = max(1, -(-2 * cores // n_batch))
+    sample = np.ascontiguousarray(np.tile(cts, (tiles, 1)))
+    idx = np.ascontiguousarray(np.tile(np.asarray(lut_sel, dtype=np.uint32), tiles))
+    big_out = np.zeros_like(sample)
+    t0 = time.perf_counter()
+    L.orc_ks_pbs_batch(C.byref(op.c()), ksk, fbsk.ctypes.data_as(C.c_void_p), None, 0, sample,
+                       idx.ctypes.data_as(C.c_void_p), luts, big_out, sample.shape[0], cores)
+    dt = time.perf_counter() - t0
+    out = big_out[:n_batch]
+    # the 16-thread figure of rounds 1-2, for continuity
     t0 = time.perf_counter()
     L.orc_ks_pbs_batch(C.byref(op.c()), ksk, fbsk.ctypes.data_as(C.c_void_p), None, 0, cts,
-                       idx.ctypes.data_as(C.c_void_p), luts, out, cts.shape[0], cores)
-    dt = time.perf_counter() - t0
+                       idx[:n_batch].ctypes.data_as(C.c_void_p), luts, np.zeros_like(cts), n_batch, min(16, cores))
+    dt16 = time.perf_counter() - t0
     # also one thread alone (ms per KS+PBS), and which CPU this was
     one = np.zeros_like(cts[:8])
     t0 = time.perf_counter()
@@ -84,10 +97,13 @@ def cpu_baseline(P, bsk, ksk, cts, lut_tables, lut_sel):
             model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
     except OSError:
         pass
-    return {"value": cts.shape[0] / dt, "unit": "PBS/s", "cores": cores, "kind": "port",
+    return {"value": sample.shape[0] / dt, "unit": "PBS/s", "cores": cores, "kind": "port",
             "single_thread_ms_per_pbs": single_ms, "cpu_model": model, "nproc": os.cpu_count(),
-            "sample": f"the same {cts.shape[0]}-LWE batch, KS+PBS per LWE, {cores} host threads over LWEs "
-                      f"(oracle/tfhe_oracle.c, gcc -O3; reference publishes 16.6 ms/PBS/core on Xeon 8375C)",
+            "pbs_per_s_16_threads": n_batch / dt16,
+            "sample": f"the same {n_batch}-LWE batch tiled x{tiles} ({sample.shape[0]} KS+PBS, about "
+                      f"{sample.shape[0] * single_ms / 1e3:.0f} CPU-seconds), one LWE per task over {cores} host threads = all "
+                      f"hardware threads of the box (oracle/tfhe_oracle.c, gcc -O3 -march=native; its plain radix-4 FFT is ~2.7x slower "
+                      f"per core than the reference's published 16.6 ms/PBS on a Xeon 8375C)",
             "seconds": dt}, out
 
 
@@ -227,8 +243,8 @@ def flop_per_cmux_step(P):
 def rooflines(P, B, world, value, br_avg_ms, revision, log2_points):
     """The `roofline` object of the bench contract (HBM, SURVEY 8(d)'s per-LWE key-streaming model for the
     dominant kernel) and, next to it, what actually bounds that kernel: f64 VALU issue + LDS
-    (`roofline_compute`).  Counter-derived fields come from the committed rocprofv3 passes
-    (profiles/r02_counters.json, one --pmc pass per counter set, scripts/prof_round.sh) and are only
+    (`roofline`; SURVEY's model is `roofline_hbm_model`).  Counter-derived fields come from the committed rocprofv3 passes
+    (profiles/r03_counters.json, one --pmc pass per counter set, scripts/prof_round.py) and are only
     attached when they were taken on this kernel revision, batch and variant."""
     br_bytes = P.bsk_len * 8 + P.glwe_len * 8 + P.small_size * 8 + P.big_size * 8   # BSK + LUT + LWE in/out
     achieved = br_bytes * B / (br_avg_ms * 1e-3) / 1e9
@@ -239,7 +255,7 @@ def rooflines(P, B, world, value, br_avg_ms, revision, log2_points):
         cj = json.load(open(COUNTERS))
         c = cj["blind_rotate_kernel"]
         if c["batch"] == B and log2_points == 0 and cj.get("kernel_revision") == revision:
-            ctr, src = c, "profiles/r02_counters.json (static: rocprofv3 --pmc passes of this kernel revision, " + cj.get("command", "") + ")"
+            ctr, src = c, "profiles/r03_counters.json (static: rocprofv3 --pmc passes of this kernel revision, " + cj.get("command", "") + ")"
     except Exception:
         pass
     traffic = ctr["traffic_bytes_per_launch"] if ctr else None
@@ -249,7 +265,7 @@ def rooflines(P, B, world, value, br_avg_ms, revision, log2_points):
             "algorithmic_bytes_per_lwe": br_bytes, "lwes_per_launch": B,
             "model": "per-LWE key streaming (SURVEY 8(d)): every LWE is charged the whole Fourier key",
             "note": "NOT the binding resource: the 48.6 MB key is shared by all workgroups and served from "
-                    "L2 / Infinity Cache; see measured_hbm_* (fabric-side bytes) and roofline_compute"}
+                    "L2 / Infinity Cache; see measured_hbm_* (fabric-side bytes) and `roofline`"}
     if traffic:
         roof["measured_hbm_gbs"] = traffic / (br_avg_ms * 1e-3) / 1e9
         roof["measured_hbm_frac"] = roof["measured_hbm_gbs"] / HBM_PEAK_GBS
@@ -278,7 +294,14 @@ def rooflines(P, B, world, value, br_avg_ms, revision, log2_points):
                      "L2 / Infinity Cache that model can exceed the HBM peak (frac_of_peak > 1 means "
                      "cache-served, not skipped work: verified_decrypt covers the timed output); the "
                      "batch-amortised compulsory traffic is the HBM-side floor"}
-    return {"roofline": roof, "roofline_compute": comp, "whole_pbs_hbm_model": whole}
+    # `roofline` = the resource that binds this kernel (f64 vector issue + the dependent LDS/barrier chain, DESIGN.md
+    # section 3), with the measured HBM-side bytes as `traffic`; SURVEY 8(d)'s per-LWE key-streaming model is kept
+    # as `roofline_hbm_model`, labelled as what it is
+    comp["traffic"] = traffic
+    comp["traffic_source"] = src
+    comp["avg_launch_ms"] = br_avg_ms
+    roof["bound"] = "hbm (SURVEY 8(d) model, not binding)"
+    return {"roofline": comp, "roofline_hbm_model": roof, "whole_pbs_hbm_model": whole}
 
 
 def bench_p44(fhestr, local_rank):
@@ -316,17 +339,43 @@ def bench_p44(fhestr, local_rank):
         ks_ms, br_ms, calls = eng.kernel_times(reset=True)
         ok = bool(np.array_equal(ck.decrypt(d_out.cpu().numpy().view(np.uint64)), table[msgs]))
         pbs_bytes = P.bsk_len * 8 + P.ksk_len * 8 + 2 * P.big_size * 8 + P.glwe_len * 8   # 3,919,314,960
+        br_avg_ms = br_ms / max(calls, 1)
+        clusters = eng.cluster_info()
         out = {"params": P.name, "batch": B, "device_keygen_s": keygen_s, "pbs_per_s": B / dt, "ms_per_step": dt * 1e3,
-               "kernel_ms": {"keyswitch": ks_ms / max(calls, 1), "blind_rotate": br_ms / max(calls, 1)},
+               "kernel_ms": {"keyswitch": ks_ms / max(calls, 1), "blind_rotate": br_avg_ms},
+               "kernel": "blind_rotate_cluster_kernel" if clusters else "blind_rotate_large_kernel",
+               "clusters_formed": clusters,
                "verified_decrypt": ok,
                "hbm_model": {"bytes_per_pbs": pbs_bytes, "frac_of_peak": B / dt * pbs_bytes / (HBM_PEAK_GBS * 1e9),
                              "note": "SURVEY 8(d) per-LWE key-streaming model; bound 2.04 k PBS/s per GPU"}}
+        # small batches: one LWE is worked on by a cluster of CUs, so latency no longer equals the 256-LWE step
+        lat = {}
+        for nb in (1, 32):
+            eng.apply_lookup_table_dev(d_in.data_ptr(), d_idx.data_ptr(), d_out.data_ptr(), nb)
+            eng.synchronize()
+            eng.kernel_times(reset=True)
+            eng.apply_lookup_table_dev(d_in.data_ptr(), d_idx.data_ptr(), d_out.data_ptr(), nb)
+            eng.synchronize()
+            k1, b1, c1 = eng.kernel_times(reset=True)
+            lat[str(nb)] = {"keyswitch_ms": k1 / max(c1, 1), "blind_rotate_ms": b1 / max(c1, 1)}
+        out["small_batch_kernel_ms"] = lat
+        # roofline of the dominant kernel from the committed counters of this kernel revision: the bytes that crossed
+        # the L2 <-> fabric boundary (FETCH_SIZE doubled for 16-byte-per-lane reads per MI355X_MICROARCH.md, WRITE_SIZE
+        # as is, separate --pmc passes) against the HBM peak; algorithmic bytes = the cluster's exchange matrices
+        # (4 MB per LWE-step: 2 out + 2 back) + the 2 MB GGSW once per XCD and step
         try:
-            c = json.load(open(COUNTERS)).get("blind_rotate_large_kernel")
-            if c and c.get("batch") == B:
-                out["measured_hbm"] = {"traffic_bytes_per_launch": c["traffic_bytes_per_launch"],
-                                       "gbs": c["traffic_bytes_per_launch"] / (br_ms / max(calls, 1) * 1e-3) / 1e9,
-                                       "source": "profiles/r02_counters.json (static rocprofv3 --pmc passes)"}
+            cj = json.load(open(COUNTERS))
+            c = cj.get(out["kernel"])
+            if c and c.get("batch") == B and cj.get("kernel_revision") == fhestr.kernel_revision():
+                steps = P.n
+                algo = B * steps * 4 * (1 << 20) + steps * 8 * (P.bsk_len * 8 // P.n)
+                out["roofline"] = {"bound": "hbm", "kernel": out["kernel"], "avg_launch_ms": br_avg_ms,
+                                   "algorithmic_bytes_per_launch": algo,
+                                   "achieved": algo / (br_avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": algo / (br_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "traffic": c["traffic_bytes_per_launch"], "l2_hit_rate": c.get("l2_hit_rate"),
+                                   "traffic_gbs": c["traffic_bytes_per_launch"] / (br_avg_ms * 1e-3) / 1e9,
+                                   "traffic_source": "profiles/r03_counters.json (static rocprofv3 --pmc passes, " + cj.get("p44_command", "") + ")"}
         except Exception:
             pass
         # config 5: 1024-char string, to_lower and replace (4-char clear pattern), one call each
@@ -432,27 +481,37 @@ def main():
     elapsed = time.perf_counter() - t0
     ks_ms, br_ms, calls = eng.kernel_times(reset=True)
     eng.set_pipeline(False)
+    got = d_out.cpu().numpy().view(np.uint64).copy()      # the TIMED loop's output, before anything else writes
     serial = None
     if not args.serial:        # the same steps one after the other (what a single dependent chain of calls gets)
         n_serial = min(args.steps, 10)
-        step()
+        d_out_serial = torch.zeros_like(d_in)
+
+        def serial_step():
+            eng.apply_lookup_table_dev(d_in.data_ptr(), d_idx.data_ptr(), d_out_serial.data_ptr(), B)
+
+        serial_step()
         eng.synchronize()
         t1 = time.perf_counter()
         for _ in range(n_serial):
-            step()
+            serial_step()
         eng.synchronize()
         serial_dt = (time.perf_counter() - t1) / n_serial
         s_ks, s_br, s_calls = eng.kernel_times(reset=True)
-        serial = {"ms_per_step": serial_dt * 1e3, "pbs_per_s_per_gpu": B / serial_dt,
+        serial_ok = bool(np.array_equal(ck.decrypt(d_out_serial.cpu().numpy().view(np.uint64)), tables[sel, msgs]))
+        serial = {"ms_per_step": serial_dt * 1e3, "pbs_per_s_per_gpu": B / serial_dt, "verified_decrypt": serial_ok,
                   "kernel_ms": {"keyswitch": s_ks / max(s_calls, 1), "blind_rotate": s_br / max(s_calls, 1)}}
+    per_rank_elapsed = [elapsed]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+        every = torch.zeros(world, dtype=torch.float64, device=coll_dev)
+        dist.all_gather_into_tensor(every, t)
+        per_rank_elapsed = [float(v) for v in every.cpu()]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
 
-    # ---- correctness gate on the timed output: decrypt == LUT(message) for every LWE ----
-    got = d_out.cpu().numpy().view(np.uint64)
+    # ---- correctness gate on the timed (pipelined unless --serial) output: decrypt == LUT(message) for every LWE ----
     dec = ck.decrypt(got)
     verified = bool(np.array_equal(dec, tables[sel, msgs]))
     if world > 1:
@@ -518,6 +577,8 @@ def main():
                           "keyswitch of step k+1 on a second stream, co-resident with the blind rotation of step k "
                           "(fhe_engine_set_pipeline); kernel_ms.keyswitch is that 64-register variant's duration while sharing the CUs"),
             "serial": serial,
+            # every rank's own rate over the same timed steps: value = the sum of the batches / the slowest rank's time
+            "per_rank_pbs_per_s": [B * args.steps / e for e in per_rank_elapsed],
             "verified_decrypt": verified,
             **({"rehearsal": "all ranks share GPU 0 (gloo, host-staged gathers): code-path check only, not a measurement"}
                if rehearsal else {}),
@@ -529,9 +590,9 @@ def main():
         if serial:   # the same kernel when nothing shares the CUs with it (the serial comparison steps)
             alone = rooflines(P, B, world, value, serial["kernel_ms"]["blind_rotate"], fhestr.kernel_revision(), args.log2_points)
             rec["roofline"]["kernel_alone"] = {"avg_launch_ms": serial["kernel_ms"]["blind_rotate"], "frac": alone["roofline"]["frac"]}
-            rec["roofline_compute"]["kernel_alone"] = {"avg_launch_ms": serial["kernel_ms"]["blind_rotate"],
-                                                       "frac": alone["roofline_compute"]["frac"]}
-            rec["roofline"]["note"] += "; avg_launch_ms is measured with the next step's keyswitch co-resident (pipelined mode), kernel_alone without"
+            rec["roofline_hbm_model"]["kernel_alone"] = {"avg_launch_ms": serial["kernel_ms"]["blind_rotate"],
+                                                         "frac": alone["roofline_hbm_model"]["frac"]}
+            rec["roofline"]["note"] = "avg_launch_ms is measured with the next step's keyswitch co-resident (pipelined mode), kernel_alone without"
 
 
     # ---- FheString ms/op (BASELINE.json configs 3 and 4): level batches sharded over the ranks, one

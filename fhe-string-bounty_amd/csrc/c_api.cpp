@@ -112,6 +112,14 @@ int fhe_engine_set_pipeline(fhe_engine* eng, int on) {
     API_END
 }
 
+int fhe_engine_pipeline_input_event(fhe_engine* eng, void* hip_event) {
+    API_BEGIN
+    CHECK_PTR(eng);
+    eng->impl->pipe_input_ready = reinterpret_cast<hipEvent_t>(hip_event);
+    return 0;
+    API_END
+}
+
 int fhe_engine_set_multibit_combine_max(fhe_engine* eng, uint32_t max_batch) {
     API_BEGIN
     CHECK_PTR(eng);

@@ -52,7 +52,8 @@ struct Engine {
     int cu_count = 256;
     bool pipeline = false;                    // ks_pbs_dev: keyswitch of call k+1 in the shadow of the blind rotation of call k
     hipStream_t ks_stream = nullptr;
-    hipEvent_t pipe_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // keyswitch done [slot], blind rotation done [slot]
+    hipEvent_t pipe_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // keyswitch done [slot], blind rotation done [slot], engine stream so far
+    hipEvent_t pipe_input_ready = nullptr;    // caller's event the next pipelined keyswitch waits for (one shot)
     const void* pipe_out[2] = {nullptr, nullptr};
     size_t pipe_out_bytes[2] = {0, 0};
     uint64_t pipe_calls = 0;

@@ -816,6 +816,16 @@ int Engine::ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint
         const size_t big = (size_t)p.k * p.N + 1;
         const char *in_lo = (const char*)d_big_in, *in_hi = in_lo + (size_t)count * big * 8;
         const char* prev = (const char*)pipe_out[slot ^ 1];
+        if (pipe_calls == 0) {
+            // first pipelined call after anything else: whatever the engine stream already holds -- a serial call's
+            // keyswitch / blind rotation that still use d_small, uploads, a caller's kernels -- comes first
+            HIP_TRY(hipEventRecord(pipe_ev[4], stream));
+            HIP_TRY(hipStreamWaitEvent(ks_stream, pipe_ev[4], 0));
+        }
+        if (pipe_input_ready) {       // fhe_engine_pipeline_input_event: the producer of this call's input
+            HIP_TRY(hipStreamWaitEvent(ks_stream, pipe_input_ready, 0));
+            pipe_input_ready = nullptr;
+        }
         if (pipe_calls >= 1 && prev && in_lo < prev + pipe_out_bytes[slot ^ 1] && prev < in_hi)
             HIP_TRY(hipStreamWaitEvent(ks_stream, pipe_ev[2 + (slot ^ 1)], 0));              // chained: input = previous output
         if (pipe_calls >= 2) HIP_TRY(hipStreamWaitEvent(ks_stream, pipe_ev[2 + slot], 0));    // blind rotation that read `sm` two calls ago
@@ -838,6 +848,7 @@ int Engine::ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint
         pipe_calls = 0;
         pipe_out[0] = pipe_out[1] = nullptr;
     }
+    pipe_input_ready = nullptr;           // serial calls are stream-ordered: nothing to wait for
     HIP_TRY(hipEventRecord(e4[0], stream));
     if (launch_keyswitch(d_big_in, d_small, count)) return 1;
     HIP_TRY(hipEventRecord(e4[1], stream));
@@ -992,6 +1003,8 @@ int Engine::synchronize() {
     if (use()) return 1;
     if (ks_stream) HIP_TRY(hipStreamSynchronize(ks_stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    pipe_calls = 0;                       // both streams are idle: the next pipelined call starts a new run
+    pipe_out[0] = pipe_out[1] = nullptr;
     return cluster_check();
 }
 

@@ -83,11 +83,20 @@ int fhe_engine_set_variant(fhe_engine *eng, int log2_points);
 /* Throughput mode for back-to-back fhe_ks_pbs_batch_dev calls on the engine's own stream (off by default): the
  * keyswitch of call k+1 runs on a second stream, in a 64-register variant whose waves are co-resident with the blind
  * rotation of call k, so it costs (almost) no time of its own: 99.4 k instead of 93.8 k PBS/s on 256-LWE batches of
- * PARAM_MESSAGE_2_CARRY_2.  Results are bit-identical.  Calls are treated as independent batches: the engine orders
- * a call after an earlier one only where its input overlaps that call's output; as always the input buffer must be
- * complete when the call is made, and outputs are valid after fhe_engine_synchronize.  Applies to batches of at
- * most one LWE per CU on the register/LDS-resident kernels; other calls run serially as before. */
+ * PARAM_MESSAGE_2_CARRY_2.  Results are bit-identical.  Applies to batches of at most one LWE per CU on the
+ * register/LDS-resident kernels; other calls run serially as before.
+ * ORDERING CONTRACT (differs from the serial mode, where every call is ordered on the engine stream): calls are
+ * treated as independent batches.  The engine orders a pipelined call after (a) everything enqueued on the engine
+ * stream before the FIRST pipelined call of a run (a run ends with any serial call or synchronisation), (b) an
+ * earlier pipelined call whose OUTPUT range overlaps this call's input, (c) the event given through
+ * fhe_engine_pipeline_input_event.  Anything else that produces the input -- a kernel or copy the caller enqueued on
+ * fhe_engine_stream() between two pipelined calls -- must either be complete on the host or be handed over as such
+ * an event; without it the second-stream keyswitch may read the input before it is written.  Outputs are valid
+ * after fhe_engine_synchronize. */
 int fhe_engine_set_pipeline(fhe_engine *eng, int on);
+/* One shot: the keyswitch of the NEXT pipelined fhe_ks_pbs_batch_dev call waits for `hip_event` (a hipEvent_t the caller
+ * recorded behind the work that produces that call's input, on any stream).  Ignored by serial calls. */
+int fhe_engine_pipeline_input_event(fhe_engine *eng, void *hip_event);
 /* Multi-bit PBS only: batches of up to max_batch LWEs build every (LWE, group) GGSW on the whole GPU first
  * (prepare_multi_bit_ggsw, lwe_multi_bit_programmable_bootstrapping.rs:18-83, which the reference runs on
  * separate threads) and then rotate against them; larger batches fuse both into one kernel.  Default 64

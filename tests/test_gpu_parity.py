@@ -425,6 +425,56 @@ def test_pipelined_calls_are_bit_identical_to_serial_ones(p22):
 
 
 @pytest.mark.gpu
+def test_pipelined_call_right_after_a_serial_one_and_stream_ordered_inputs(p22):
+    """(a) with the throughput mode on, a batch that takes the serial path (more LWEs than CUs) followed at
+    once, without synchronisation, by one that takes the pipelined path -- both use the engine's small-ciphertext buffer;
+    (b) an input produced by work enqueued on the engine stream between two pipelined calls, handed over with
+    fhe_engine_pipeline_input_event.  Bit-identical to serial calls."""
+    import torch
+    ks = p22
+    eng = gpu_engine(ks)
+    p = ks.params
+    M = p.msg_mod * p.carry_mod
+    lut, _ = eng.generate_lookup_table(lambda x: (5 * x + 2) % M)
+    rng = np.random.default_rng(23)
+    big_b, small_b = 512, 96
+    big = torch.from_numpy(ks.ck.encrypt_many(rng.integers(0, M, size=big_b)).view(np.int64)).cuda()
+    small = torch.from_numpy(ks.ck.encrypt_many(rng.integers(0, M, size=small_b)).view(np.int64)).cuda()
+    idx = torch.full((big_b,), int(lut), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+
+    def run(pipelined):
+        eng.set_pipeline(pipelined)
+        o_big, o_small, o_late = torch.zeros_like(big), torch.zeros_like(small), torch.zeros_like(small)
+        for _ in range(3):           # serial-path batch, then at once a pipelined one
+            eng.apply_lookup_table_dev(big.data_ptr(), idx.data_ptr(), o_big.data_ptr(), big_b)
+            eng.apply_lookup_table_dev(small.data_ptr(), idx.data_ptr(), o_small.data_ptr(), small_b)
+        # (b) the input of the next call is written by copies on the engine stream, enqueued after the previous call
+        stream = torch.cuda.ExternalStream(eng.stream)
+        staged = torch.zeros_like(small)
+        ballast_src = torch.zeros(64 << 20, dtype=torch.int64, device="cuda")      # 512 MB: keeps the stream busy for a while
+        ballast_dst = torch.empty_like(ballast_src)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            for _ in range(4):
+                ballast_dst.copy_(ballast_src, non_blocking=True)
+            staged.copy_(small, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        if pipelined:
+            eng.pipeline_input_event(ev.cuda_event)
+        eng.apply_lookup_table_dev(staged.data_ptr(), idx.data_ptr(), o_late.data_ptr(), small_b)
+        eng.synchronize()
+        eng.set_pipeline(False)
+        return [t.cpu().numpy() for t in (o_big, o_small, o_late)]
+
+    serial, piped = run(False), run(True)
+    assert all(np.array_equal(a, b) for a, b in zip(serial, piped))
+    assert np.array_equal(serial[1], serial[2])
+    assert np.array_equal(ks.ck.decrypt_many(piped[1].view(np.uint64))[:8], ks.ck.decrypt_many(serial[2].view(np.uint64))[:8])
+
+
+@pytest.mark.gpu
 def test_blind_rotation_against_an_exact_integer_recurrence():
     """Known-answer test of the rotate-subtract-decompose-accumulate chain (polynomial_algorithms.rs:315-354,425-490,
     decomposer.rs:98-118, bootstrap.rs:242-331) that needs neither the oracle nor its FFT: with an all-zero GLWE
