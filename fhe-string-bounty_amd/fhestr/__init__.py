@@ -200,7 +200,7 @@ def lib() -> C.CDLL:
     sig("fhe_engine_set_variant", vp, i32)
     sig("fhe_engine_set_multibit_combine_max", vp, u32)
     sig("fhe_engine_set_pipeline", vp, i32)
-    sig("fhe_engine_set_cluster_mode", "fhe_engine_pipeline_input_event", vp, i32, u32)
+    sig("fhe_engine_set_cluster_mode", vp, i32, u32)
     sig("fhe_engine_cluster_info", vp, C.POINTER(u32))
     sig("fhe_engine_load_seeded_keys", vp, vp, vp, vp, vp, vp, vp)
     sig("fhe_engine_expand_seeded_lwe", vp, vp, vp, u32, vp, vp)

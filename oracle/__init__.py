@@ -354,6 +354,23 @@ class ServerKey:
             self.fbsk = np.zeros(self.bsk.size, dtype=np.float64)
             lib().orc_bsk_to_fourier(C.byref(pc), self.bsk, self.fbsk)
 
+    @classmethod
+    def from_keys(cls, params: Params, bsk, ksk, threads: int | None = None, fourier: bool = True):
+        """Oracle operators over server keys made elsewhere (standard-domain layouts of SURVEY.md 8(a)), e.g. the keys the
+        GPU engine generated and exported: the checker then runs on exactly the key material the device kernels use."""
+        self = cls.__new__(cls)
+        self.params = params
+        self.threads = threads or min(8, os.cpu_count() or 1)
+        self.ksk = _a(ksk).reshape(-1)
+        self.bsk = _a(bsk).reshape(-1)
+        assert self.ksk.size == params.big_dim * params.ks_level * params.small_size
+        assert self.bsk.size == params.n * params.pbs_level * (params.k + 1) ** 2 * params.N
+        self.fbsk = None
+        if fourier:
+            self.fbsk = np.zeros(self.bsk.size, dtype=np.float64)
+            lib().orc_bsk_to_fourier(C.byref(params.c()), self.bsk, self.fbsk)
+        return self
+
     # shortint/server_key/mod.rs:383-399
     def generate_lookup_table(self, f):
         p = self.params

@@ -99,10 +99,130 @@ def measure(ks, eng, samples=8192, chunk=1024, seed=0x5EED0004):
     return out
 
 
+def reference_params(name):
+    """fhestr.Params of a parameter set of the reference, from tests/golden/reference_parameter_sets.json
+    (read out of shortint/parameters/{mod,multi_bit}.rs by tests/golden/make_param_table.py)."""
+    import fhestr
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_parameter_sets.json")))[name]
+    return fhestr.Params(d["lwe_dimension"], d["glwe_dimension"], d["polynomial_size"], d["pbs_base_log"], d["pbs_level"],
+                         d["ks_base_log"], d["ks_level"], d["message_modulus"], d["carry_modulus"], d["lwe_modular_std_dev"],
+                         d["glwe_modular_std_dev"], name, grouping=d.get("grouping_factor", 1) or 1)
+
+
+def measure_product(P, shapes, samples=2048, chunk=512, seed=0x5EED0014, eng=None, ck=None):
+    """The same measurement for ANY parameter set, on device-generated keys with the product client (no oracle):
+    `shapes` = {name: coefficient list}; every coefficient multiplies its own nominal ciphertext (an identity-PBS
+    output); shapes whose coefficients would push the value out of the message space use encryptions of 0 (the noise
+    does not depend on the message).  Returns per shape the spread after keyswitch and after the modulus switch next to
+    the model's (csrc/noise_model.h), and the PBS output noise next to the model's V_pbs."""
+    import fhestr
+    own = eng is None
+    if own:
+        ck = fhestr.ClientKey(P, seed)
+        g, s = ck.secret_keys()
+        eng = fhestr.Engine(P, 0)
+        eng.generate_keys(g, s, seed)
+    else:
+        g, s = ck.secret_keys()
+    try:
+        logN = P.N.bit_length() - 1
+        Mtot = P.msg_mod * P.carry_mod
+        delta = (1 << 63) // Mtot
+        ident, _ = eng.generate_lookup_table(lambda x: x)
+        big_sel, small_sel = np.flatnonzero(g == 1), np.flatnonzero(s == 1)
+        m = fhestr.noise_model(P)
+        width = max(len(c) for c in shapes.values())
+        errs = {k: {"ks": [], "ms": []} for k in shapes}
+        pbs_err = None
+        rng = np.random.default_rng(seed)
+        done = 0
+        while done < samples:
+            S = min(chunk, samples - done)
+            msgs = np.zeros((width, S), dtype=np.int64)
+            # small random messages where every shape's value provably stays inside the message space, else zeros
+            worst = max(sum(abs(c) for c in co) for co in shapes.values())
+            top = max(1, min(P.msg_mod, Mtot // max(1, worst)))
+            msgs[:] = rng.integers(0, top, size=(width, S))
+            fresh = ck.encrypt(msgs.reshape(-1))
+            nominal = eng.apply_lookup_table(fresh, np.full(width * S, ident, dtype=np.uint32))
+            if pbs_err is None:
+                sub = nominal[: min(512, width * S)]
+                with np.errstate(over="ignore"):
+                    ph = sub[:, -1] - sub[:, big_sel].sum(axis=1, dtype=np.uint64)
+                    e = (ph - msgs.reshape(-1)[: sub.shape[0]].astype(np.uint64) * np.uint64(delta)).astype(np.int64)
+                pbs_err = e.astype(np.float64) / 2.0**64
+            for name, co in shapes.items():
+                jobs = [([(r * S + i, c) for r, c in enumerate(co) if c], 0) for i in range(S)]
+                value = sum(c * msgs[r] for r, c in enumerate(co))
+                small = eng.keyswitch(eng.lincomb(nominal, jobs))
+                want = value.astype(np.int64).astype(np.uint64) * np.uint64(delta)
+                with np.errstate(over="ignore"):
+                    phase = small[:, -1] - small[:, small_sel].sum(axis=1, dtype=np.uint64)
+                    e_ks = (phase - want).astype(np.int64).astype(np.float64) / 2.0**64
+                    ms = ((small >> np.uint64(64 - logN - 2)) + np.uint64(1)) >> np.uint64(1)
+                    ph_ms = (ms[:, -1].astype(np.int64) - ms[:, small_sel].astype(np.int64).sum(axis=1)) % (2 * P.N)
+                    want_ms = (want.astype(np.float64) / 2.0**64) * (2 * P.N)
+                    d = (ph_ms - want_ms + P.N) % (2 * P.N) - P.N
+                errs[name]["ks"].append(e_ks)
+                errs[name]["ms"].append(d / (2 * P.N))
+            done += S
+        half = m["half_box"]
+        out = {"params": P.name, "samples": samples, "half_box": half, "model": m,
+               "pbs_out_std": float(np.std(pbs_err)), "pbs_out_std_model": math.sqrt(m["v_pbs"]),
+               "pbs_out_samples": int(pbs_err.size)}
+        for name, co in shapes.items():
+            ks_e, ms_e = np.concatenate(errs[name]["ks"]), np.concatenate(errs[name]["ms"])
+            nu = float(sum(c * c for c in co))
+            model_std = math.sqrt(nu * m["v_pbs"] + m["v_ks"] + m["v_ms"])
+            out[name] = {"norm2_sq": nu, "n": int(ks_e.size), "std_after_ks": float(ks_e.std()), "std_after_ms": float(ms_e.std()),
+                         "std_after_ms_model": model_std, "mean_after_ms": float(ms_e.mean()),
+                         "max_abs_after_ms": float(np.abs(ms_e).max()), "log2_pfail_gauss": log2_pfail(float(ms_e.std()), half),
+                         "log2_pfail_model": log2_pfail(model_std, half)}
+        return out
+    finally:
+        if own:
+            eng.close()
+
+
+# shapes per parameter set: the reference's own worst case (one ciphertext scaled by max_noise_level,
+# shortint/ciphertext/mod.rs:28-55), one ciphertext scaled up to this engine's budget (csrc/noise_model.h), and
+# what the string / integer builders actually pack (encryptions of 0 where the value would leave the message space)
+SETS = {
+    "p22": ("PARAM_MESSAGE_2_CARRY_2_KS_PBS", {"find_135": [8, 8, 2, 1, 1, 1], "packed_34": [1, 4, -1, -4]}),
+    "p44": ("PARAM_MESSAGE_4_CARRY_4_KS_PBS", {"whole_char_257": [16, 1], "packed_514": [1, 16, -1, -16]}),
+    "n8192_l2": ("PARAM_MESSAGE_3_CARRY_3_KS_PBS", {"whole_char_65": [8, 1]}),
+    "n8192_l1": ("PARAM_MESSAGE_5_CARRY_1_KS_PBS", {}),
+    "n4096": ("PARAM_MESSAGE_2_CARRY_3_KS_PBS", {}),
+    "n16384": ("PARAM_MESSAGE_3_CARRY_4_KS_PBS", {}),
+    "n1024": ("PARAM_MESSAGE_2_CARRY_1_KS_PBS", {}),
+    "mb_g3": ("PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS", {"packed_34": [1, 4, -1, -4]}),
+    "mb_g2": ("PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS", {"packed_34": [1, 4, -1, -4]}),
+}
+
+
+def shapes_for(P, extra):
+    import fhestr
+    m = fhestr.noise_model(P)
+    max_level = (P.msg_mod * P.carry_mod - 1) // max(1, P.msg_mod - 1)
+    shapes = {"reference_worst": [int(max_level)], "near_budget": [max(1, int(math.sqrt(m["budget"])))]}
+    shapes.update(extra)
+    return shapes
+
+
 if __name__ == "__main__":
-    import oracle as O
-    from conftest import gpu_engine, keyset
-    ks = keyset(O.PARAM_MESSAGE_2_CARRY_2_KS_PBS)
-    eng = gpu_engine(ks)
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-    print(json.dumps(measure(ks, eng, n), indent=1))
+    args = sys.argv[1:]
+    if args and args[0] in SETS or (args and args[0] == "all"):
+        n = int(args[1]) if len(args) > 1 else 4096
+        res = {}
+        for key in (SETS if args[0] == "all" else [args[0]]):
+            name, extra = SETS[key]
+            P = reference_params(name)
+            res[key] = measure_product(P, shapes_for(P, extra), samples=n)
+            print(key, json.dumps(res[key]), flush=True)
+    else:
+        import oracle as O
+        from conftest import gpu_engine, keyset
+        ks = keyset(O.PARAM_MESSAGE_2_CARRY_2_KS_PBS)
+        eng = gpu_engine(ks)
+        n = int(args[0]) if args else 8192
+        print(json.dumps(measure(ks, eng, n), indent=1))

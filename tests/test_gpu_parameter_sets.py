@@ -72,3 +72,74 @@ def test_reference_parameter_set_decrypts(name):
         assert np.array_equal(ck.decrypt(out), table[msgs])
     finally:
         eng.close()
+
+
+# One parameter set per blind-rotation kernel family (csrc/engine.hip, variants()): N = 256 (k = 5), 512 (k = 3 and k = 2 with
+# two levels), 1024 (k = 2), 2048, 4096 (one and two levels), 8192 (seq kernel, one and two levels), 16384 and 32768 (cluster
+# kernel, two and three levels).
+FAMILIES = ["PARAM_MESSAGE_1_CARRY_0_KS_PBS", "PARAM_MESSAGE_1_CARRY_1_KS_PBS", "PARAM_MESSAGE_2_CARRY_0_KS_PBS",
+            "PARAM_MESSAGE_2_CARRY_1_KS_PBS", "PARAM_MESSAGE_2_CARRY_2_KS_PBS", "PARAM_MESSAGE_2_CARRY_3_KS_PBS",
+            "PARAM_MESSAGE_1_CARRY_4_KS_PBS", "PARAM_MESSAGE_5_CARRY_1_KS_PBS", "PARAM_MESSAGE_3_CARRY_3_KS_PBS",
+            "PARAM_MESSAGE_3_CARRY_4_KS_PBS", "PARAM_MESSAGE_1_CARRY_6_KS_PBS", "PARAM_MESSAGE_3_CARRY_5_KS_PBS"]
+
+
+def _oracle_params(P):
+    import oracle as O
+    return O.Params(P.n, P.k, P.N, P.pbs_base_log, P.pbs_level, P.ks_base_log, P.ks_level, P.msg_mod, P.carry_mod,
+                    P.lwe_std, P.glwe_std, P.name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FAMILIES)
+def test_kernel_family_against_the_oracle_on_exported_device_keys(name):
+    """Real dimensions, device-generated keys EXPORTED in the reference's layouts and handed to the CPU
+    oracle: the oracle's keyswitch of the same ciphertexts is bit-identical, its KS + PBS decrypts to the same messages and
+    its output phases sit within 8 sigma (noise model) of the device's.  Decrypt-only checks on device keys would let a
+    layout error shared by device keygen and device PBS cancel; this cannot."""
+    import fhestr
+    import oracle as O
+    from conftest import torus_distance
+    P = _params(name)
+    M = P.msg_mod * P.carry_mod
+    ck = fhestr.ClientKey(P, 0x5E8)
+    g, s = ck.secret_keys()
+    eng = fhestr.Engine(P, 0)
+    try:
+        bsk, ksk = eng.generate_keys(g, s, 0x5E8, export=True)
+        osk = O.ServerKey.from_keys(_oracle_params(P), bsk, ksk, threads=8)
+        f = lambda x: (5 * x + 1) % M
+        lut_id, _ = eng.generate_lookup_table(f)
+        lut, _ = osk.generate_lookup_table(f)
+        msgs = np.array([0, M - 1, M // 2, 1])
+        enc = ck.encrypt(msgs)
+        assert np.array_equal(eng.keyswitch(enc), np.stack([osk.keyswitch(c) for c in enc]))
+        got = eng.apply_lookup_table(enc, np.full(len(msgs), lut_id, dtype=np.uint32))
+        want = osk.apply_lookup_table_batch(enc, lut, threads=4)
+        assert ck.decrypt(got).tolist() == [f(int(m)) for m in msgs] == ck.decrypt(want).tolist()
+        big_sel = np.flatnonzero(g == 1)
+        phase = lambda cts: (cts[:, -1] - cts[:, big_sel].sum(axis=1, dtype=np.uint64))
+        tol = 8.0 * np.sqrt(2.0 * fhestr.noise_model(P)["v_pbs"]) * 2.0**64
+        with np.errstate(over="ignore"):
+            dist = torus_distance(phase(got), phase(want))
+        print(f"{name}: max phase distance GPU vs oracle = 2^{np.log2(dist.max() + 1):.1f} (8 sigma = 2^{np.log2(tol):.1f})")
+        assert dist.max() < tol
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["PARAM_MESSAGE_2_CARRY_1_KS_PBS", "PARAM_MESSAGE_2_CARRY_3_KS_PBS"])
+def test_device_keygen_is_bit_identical_to_the_oracle_keygen(name):
+    """N = 1024 (k = 2) and N = 4096 with their real dimensions: the device-generated KSK and standard-domain BSK equal
+    the oracle's (same secret keys, same ChaCha20 streams) word for word -- as test_gpu_parity.py asserts for P22."""
+    import fhestr
+    import oracle as O
+    P = _params(name)
+    ock = O.ClientKey(_oracle_params(P), 0x5E9)
+    osk = O.ServerKey(ock, threads=16, fourier=False)
+    eng = fhestr.Engine(P, 0)
+    try:
+        bsk, ksk = eng.generate_keys(ock.glwe_sk, ock.small_sk, 0x5E9, export=True)
+        assert np.array_equal(ksk, osk.ksk) and np.array_equal(bsk, osk.bsk)
+    finally:
+        eng.close()
