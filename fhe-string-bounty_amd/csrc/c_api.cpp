@@ -527,6 +527,10 @@ int fhe_noise_model(const fhe_params_t* params, double out[6]) {
     API_END
 }
 
+int fhe_noise_model_is_calibrated(const fhe_params_t* params) {
+    return params && fhe::noise_model_is_calibrated(*params) ? 1 : 0;
+}
+
 int fhe_plan_set_noise_budget(fhe_plan* p, double budget) {
     API_BEGIN
     PLAN_BUILDING(p);

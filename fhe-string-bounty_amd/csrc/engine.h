@@ -64,6 +64,10 @@ struct Engine {
     uint64_t* d_ksk = nullptr;       // reference layout (kept only when the byte-plane path is disabled)
     uint32_t* d_ksk_packed = nullptr; // [rows/4][8][n+1] byte planes for keyswitch_dot4_kernel
     uint64_t* d_ksk_rowsum = nullptr; // [kN / KS_IC][n+1] sums of every tile's key rows (bias removal)
+    int8_t* d_ksk_mfma = nullptr;     // balanced base-256 digit planes of the KSK in MFMA B-fragment order (ks_mfma_kernels.hip.h)
+    int8_t* d_ks_digits = nullptr;    // A fragments: signed decomposition digits of the batch being keyswitched
+    size_t cap_ks_digits = 0;
+    bool ks_mfma_enabled = true;      // FHESTR_KS_MFMA=0: byte-plane dot4 kernel everywhere
     double* d_fbsk = nullptr;
     uint64_t* d_luts = nullptr;
     size_t luts_cap = 0;

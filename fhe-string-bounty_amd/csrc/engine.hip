@@ -17,6 +17,7 @@
 
 #include "keygen_kernels.hip.h"   // first: asserts fp contract(off); the FFT header turns fusion on after it
 #include "lwe_kernels.hip.h"
+#include "ks_mfma_kernels.hip.h"
 #include "pbs_kernels.hip.h"
 #include "pbs_large_kernels.hip.h"
 #include "pbs_cluster_kernels.hip.h"
@@ -270,6 +271,7 @@ int Engine::create(const fhe_params_t& p, int device, Engine** out) {
     e->device = device;
     e->variant = v;
     e->variant_large = v;
+    if (const char* m = getenv("FHESTR_KS_MFMA")) e->ks_mfma_enabled = atoi(m) != 0;
     if (const char* m = getenv("FHESTR_CLUSTER")) e->cluster_mode = std::min(1, std::max(-1, atoi(m)));
     if (const char* m = getenv("FHESTR_MULTIBIT_COMBINE_MAX")) e->multibit_combine_max = (uint32_t)std::min(1024, std::max(0, atoi(m)));
     if (env_logr == 0) {   // automatic: "wide" twin (same points per thread => same key layout) for big batches
@@ -291,7 +293,7 @@ Engine::~Engine() {
     if (stream) (void)hipStreamSynchronize(stream);
     auto rel = [](void* ptr) { if (ptr) (void)hipFree(ptr); };
     rel(d_ksk); rel(d_ksk_packed); rel(d_ksk_rowsum); rel(d_fbsk); rel(d_luts); rel(d_in); rel(d_small); rel(d_small2); rel(d_out); rel(d_idx);
-    rel(d_pool); rel(d_meta); rel(d_ws); rel(d_slot_exp); rel(d_cluster_ws); rel(d_cluster_ctl);
+    rel(d_pool); rel(d_meta); rel(d_ws); rel(d_slot_exp); rel(d_cluster_ws); rel(d_cluster_ctl); rel(d_ksk_mfma); rel(d_ks_digits);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ring) if (e) (void)hipEventDestroy(e);
     for (auto& e : pipe_ev) if (e) (void)hipEventDestroy(e);
@@ -566,6 +568,15 @@ int Engine::install_keys(uint64_t* d_ksk_std, uint64_t* d_std) {
         d_ksk = d_ksk_std;
         d_ksk_std = nullptr;          // kept: the mad64 kernel reads the 64-bit layout
     }
+    if (d_ksk_mfma) { HIP_TRY(hipFree(d_ksk_mfma)); d_ksk_mfma = nullptr; }
+    if (use_dot4 && ks_mfma_enabled) {   // balanced base-256 digit planes in MFMA fragment order (ks_mfma_kernels.hip.h)
+        const KsMfmaGeom g = ks_mfma_geom(p.k * p.N, p.n + 1, p.ks_level, p.ks_base_log);
+        const size_t bytes = (size_t)g.col_groups * g.steps * 8 * 1024;
+        HIP_TRY(hipMalloc((void**)&d_ksk_mfma, bytes));
+        hipLaunchKernelGGL(ksk_repack_mfma_kernel, dim3(g.col_groups, g.steps), dim3(64), 0, stream, d_ksk_std, d_ksk_mfma, g);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
     HIP_TRY(hipMalloc((void**)&d_fbsk, bsk_len * 8));   // N u64 -> N/2 c64: same byte count
     if (convert_polys(d_std, d_fbsk, (uint32_t)(bsk_len / p.N))) return 1;
     if (variant->combine_generic_fn && probe_slot_exponents()) return 1;
@@ -645,6 +656,42 @@ int Engine::launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t cou
     if (count > 65535u * KSD_S) return fail("batch too large for one keyswitch launch (max 524280 LWEs)");
     const uint32_t in_dim = p.k * p.N, out_size = p.n + 1;
     HIP_TRY(hipMemsetAsync(d_sm, 0, (size_t)count * out_size * 8, s));
+    if (d_ksk_mfma && !shadow) {
+        // int8 matrix product on the matrix cores: digits -> A fragments, then 32x32x32 tiles over (samples, columns x planes, rows)
+        const KsMfmaGeom g = ks_mfma_geom(in_dim, out_size, p.ks_level, p.ks_base_log);
+        const uint32_t row_tiles = (count + 31) / 32;
+        const size_t need = (size_t)row_tiles * g.steps * 1024;
+        if (need > cap_ks_digits) {
+            if (d_ks_digits) { HIP_TRY(hipStreamSynchronize(stream)); if (ks_stream) HIP_TRY(hipStreamSynchronize(ks_stream)); HIP_TRY(hipFree(d_ks_digits)); }
+            d_ks_digits = nullptr; cap_ks_digits = 0;
+            HIP_TRY(hipMalloc((void**)&d_ks_digits, need));
+            HIP_TRY(hipMemsetAsync(d_ks_digits, 0, need, s));      // the pad slots stay zero for the buffer's lifetime
+            cap_ks_digits = need;
+        }
+        KsDecomposeArgs da{d_big, d_ks_digits, g, count};
+        hipLaunchKernelGGL(ks_decompose_kernel, dim3((2 * g.steps + 255) / 256, count), dim3(256), 0, s, da);
+        uint32_t mt = 1;
+        while (mt < 8 && mt < row_tiles) mt *= 2;
+        const uint32_t gy = (row_tiles + mt - 1) / mt;
+        // K split over workgroups: enough waves to fill the 1024 SIMDs about one and a half times, no more -- every extra
+        // chunk adds batch x columns 64-bit atomics (measured at 256 LWEs: 8 chunks 55 us, 32 chunks 89 us for memset +
+        // digits + product; scripts/ks_bench.py)
+        uint32_t chunks = (6u * (uint32_t)cu_count + g.col_groups * gy * mt / 2) / (g.col_groups * gy * mt);
+        if (const char* e = getenv("FHESTR_KS_CHUNKS")) chunks = (uint32_t)atoi(e);
+        chunks = std::max(1u, std::min(chunks, (g.steps + 7) / 8));
+        const uint32_t spc = (g.steps + chunks - 1) / chunks;
+        chunks = (g.steps + spc - 1) / spc;
+        KsMfmaArgs ma{d_big, d_ksk_mfma, d_ks_digits, d_sm, g, count, row_tiles, spc};
+        const dim3 grid(g.col_groups, gy, chunks);
+        switch (mt) {
+            case 1: hipLaunchKernelGGL(keyswitch_mfma_kernel<1>, grid, dim3(64), 0, s, ma); break;
+            case 2: hipLaunchKernelGGL(keyswitch_mfma_kernel<2>, grid, dim3(128), 0, s, ma); break;
+            case 4: hipLaunchKernelGGL(keyswitch_mfma_kernel<4>, grid, dim3(256), 0, s, ma); break;
+            default: hipLaunchKernelGGL(keyswitch_mfma_kernel<8>, grid, dim3(512), 0, s, ma); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (d_ksk_packed) {
         KeyswitchPackedArgs pa{d_big, d_ksk_packed, d_ksk_rowsum, d_sm, in_dim, out_size, p.ks_base_log, p.ks_level, count};
         if (shadow) {     // small-register variant: co-resident with the blind rotation of the previous batch

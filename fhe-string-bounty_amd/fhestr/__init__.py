@@ -146,7 +146,7 @@ EXPORTS = [
     "fhe_plan_create", "fhe_plan_destroy", "fhe_plan_input", "fhe_plan_lut", "fhe_plan_lin", "fhe_plan_pbs",
     "fhe_plan_output", "fhe_plan_finalize", "fhe_plan_info", "fhe_plan_level_info", "fhe_plan_export_level",
     "fhe_plan_run", "fhe_plan_run_level_rank_dev", "fhe_plan_gather_outputs_dev", "fhe_str_plan_create",
-    "fhe_plan_level_rank_info", "fhe_plan_noise_info", "fhe_noise_model", "fhe_plan_set_noise_budget",
+    "fhe_plan_level_rank_info", "fhe_plan_noise_info", "fhe_noise_model", "fhe_noise_model_is_calibrated", "fhe_plan_set_noise_budget",
     "fhe_plan_pbs_signed", "fhe_plan_set_owner_hint",
     "fhe_str_to_upper", "fhe_str_to_lower", "fhe_plan_create_offline", "fhe_str_plan_create_offline",
     "fhe_str_trim_start", "fhe_str_trim_end", "fhe_str_strip", "fhe_str_replace", "fhe_str_replace_clear",
@@ -244,6 +244,7 @@ def lib() -> C.CDLL:
     sig("fhe_plan_level_rank_info", vp, u32, u32, C.POINTER(u32))
     sig("fhe_plan_noise_info", vp, C.POINTER(C.c_double))
     sig("fhe_noise_model", PP, C.POINTER(C.c_double))
+    sig("fhe_noise_model_is_calibrated", PP)
     sig("fhe_plan_set_noise_budget", vp, C.c_double)
     sig("fhe_plan_pbs_signed", vp, u32, u32, C.POINTER(u32))
     sig("fhe_plan_set_owner_hint", vp, i32)
@@ -298,6 +299,11 @@ def chacha20_block(key: bytes, counter: int, stream: int) -> np.ndarray:
     kb = (C.c_uint8 * 32)(*seed_bytes(key))
     _check(lib().fhe_chacha20_block(kb, C.c_uint64(counter), C.c_uint64(stream), _ptr(out)))
     return out
+
+
+def noise_model_is_calibrated(params: "Params") -> bool:
+    """Has the model's V_pbs been checked against measured PBS output noise for this (N, k, level, grouping) shape?"""
+    return bool(lib().fhe_noise_model_is_calibrated(C.byref(params.c())))
 
 
 def noise_model(params: "Params") -> dict:

@@ -195,6 +195,9 @@ int fhe_plan_info(const fhe_plan *plan, uint32_t info[6]);
 int fhe_plan_noise_info(const fhe_plan *plan, double info[4]);
 /* out[6] = {V_pbs, V_ks, V_ms (variances, torus = 1), delta/2, default budget, log2 p_fail at it} */
 int fhe_noise_model(const fhe_params_t *params, double out[6]);
+/* 1 if the model's PBS-output variance has been checked against this engine's measured noise for the shape
+ * (N, k, level, grouping factor) of `params`; shapes that have not carry a 4x safety factor in the budget. */
+int fhe_noise_model_is_calibrated(const fhe_params_t *params);
 /* Pool layout of a level.  Every rank runs its own jobs [job_lo, job_hi) of the level (rank_info) and
  * writes job job_lo + i to pool slot local_base + i; if e_max > 0 the level ends with an all-gather of
  * the first e_max slots of every rank's local region into [recv_base, recv_base + world * e_max).
