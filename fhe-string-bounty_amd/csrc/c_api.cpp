@@ -3,6 +3,7 @@
 // every entry point catches everything and returns 0/1 (c_api/utils.rs:3-12), out-pointers are
 // nulled first so unchecked failures are loud (c_api/shortint/server_key/pbs.rs:24-29).
 #include <exception>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,14 @@ using fhe::fail;
 
 #define CHECK_PTR(p) \
     if (!(p)) return fail("null pointer: " #p)
+// Calls on one engine from several host threads are serialised here (the reference's ServerKey is Sync: every thread
+// brings its own scratch through a thread-local ShortintEngine, shortint/engine/mod.rs:23-25,184-189; this engine owns one
+// set of staging buffers and one stream, so it takes a lock instead).  Recursive: fhe_str_* build plans through the
+// same entry points.
+#define LOCK_ENGINE(e) std::lock_guard<std::recursive_mutex> _engine_lock((e)->impl->mu)
+#define LOCK_PLAN(p) \
+    std::unique_lock<std::recursive_mutex> _plan_lock; \
+    if ((p)->c->engine()) _plan_lock = std::unique_lock<std::recursive_mutex>((p)->c->engine()->mu)
 
 extern "C" {
 
@@ -56,7 +65,7 @@ int fhe_engine_params(const fhe_engine* eng, fhe_params_t* out) {
 
 int fhe_engine_load_keys(fhe_engine* eng, const uint64_t* bsk_std, const uint64_t* ksk) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(bsk_std); CHECK_PTR(ksk);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(bsk_std); CHECK_PTR(ksk);
     return eng->impl->load_keys(bsk_std, ksk);
     API_END
 }
@@ -64,7 +73,7 @@ int fhe_engine_load_keys(fhe_engine* eng, const uint64_t* bsk_std, const uint64_
 int fhe_engine_generate_keys(fhe_engine* eng, const uint64_t* glwe_sk, const uint64_t* small_sk, const uint8_t seed[32],
                              uint64_t* bsk_std_out, uint64_t* ksk_out) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(glwe_sk); CHECK_PTR(small_sk); CHECK_PTR(seed);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(glwe_sk); CHECK_PTR(small_sk); CHECK_PTR(seed);
     return eng->impl->generate_keys(glwe_sk, small_sk, seed, bsk_std_out, ksk_out);
     API_END
 }
@@ -73,14 +82,14 @@ void* fhe_engine_stream(fhe_engine* eng) { return eng ? (void*)eng->impl->stream
 
 int fhe_engine_synchronize(fhe_engine* eng) {
     API_BEGIN
-    CHECK_PTR(eng);
+    CHECK_PTR(eng); LOCK_ENGINE(eng);
     return eng->impl->synchronize();
     API_END
 }
 
 int fhe_engine_set_variant(fhe_engine* eng, int log2_points) {
     API_BEGIN
-    CHECK_PTR(eng);
+    CHECK_PTR(eng); LOCK_ENGINE(eng);
     return eng->impl->set_variant(log2_points);
     API_END
 }
@@ -88,7 +97,7 @@ int fhe_engine_set_variant(fhe_engine* eng, int log2_points) {
 int fhe_engine_load_seeded_keys(fhe_engine* eng, const uint8_t ksk_seed[16], const uint64_t* ksk_bodies, const uint8_t bsk_seed[16],
                                 const uint64_t* bsk_bodies, uint64_t* bsk_std_out, uint64_t* ksk_out) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(ksk_seed); CHECK_PTR(ksk_bodies); CHECK_PTR(bsk_seed); CHECK_PTR(bsk_bodies);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(ksk_seed); CHECK_PTR(ksk_bodies); CHECK_PTR(bsk_seed); CHECK_PTR(bsk_bodies);
     return eng->impl->load_seeded_keys(ksk_seed, ksk_bodies, bsk_seed, bsk_bodies, bsk_std_out, ksk_out);
     API_END
 }
@@ -96,7 +105,7 @@ int fhe_engine_load_seeded_keys(fhe_engine* eng, const uint8_t ksk_seed[16], con
 int fhe_engine_expand_seeded_lwe(fhe_engine* eng, const uint8_t* seeds, const uint64_t* bodies, uint32_t count, uint64_t* d_out,
                                  uint64_t* host_out) {
     API_BEGIN
-    CHECK_PTR(eng);
+    CHECK_PTR(eng); LOCK_ENGINE(eng);
     if (count) { CHECK_PTR(seeds); CHECK_PTR(bodies); }
     if (!d_out && !host_out) return fhe::fail("expand_seeded_lwe: no destination");
     return eng->impl->expand_seeded_lwe(seeds, bodies, count, d_out, host_out);
@@ -105,7 +114,7 @@ int fhe_engine_expand_seeded_lwe(fhe_engine* eng, const uint8_t* seeds, const ui
 
 int fhe_engine_set_pipeline(fhe_engine* eng, int on) {
     API_BEGIN
-    CHECK_PTR(eng);
+    CHECK_PTR(eng); LOCK_ENGINE(eng);
     if (eng->impl->synchronize()) return 1;
     eng->impl->pipeline = on != 0;
     return 0;
@@ -114,7 +123,7 @@ int fhe_engine_set_pipeline(fhe_engine* eng, int on) {
 
 int fhe_engine_pipeline_input_event(fhe_engine* eng, void* hip_event) {
     API_BEGIN
-    CHECK_PTR(eng);
+    CHECK_PTR(eng); LOCK_ENGINE(eng);
     eng->impl->pipe_input_ready = reinterpret_cast<hipEvent_t>(hip_event);
     return 0;
     API_END
@@ -122,7 +131,7 @@ int fhe_engine_pipeline_input_event(fhe_engine* eng, void* hip_event) {
 
 int fhe_engine_set_multibit_combine_max(fhe_engine* eng, uint32_t max_batch) {
     API_BEGIN
-    CHECK_PTR(eng);
+    CHECK_PTR(eng); LOCK_ENGINE(eng);
     if (max_batch > 1024) return fhe::fail("multibit_combine_max: at most 1024 (workspace grows by 16 MB per LWE at N = 2048)");
     eng->impl->multibit_combine_max = max_batch;
     return 0;
@@ -131,7 +140,7 @@ int fhe_engine_set_multibit_combine_max(fhe_engine* eng, uint32_t max_batch) {
 
 int fhe_engine_set_cluster_mode(fhe_engine* eng, int mode, uint32_t max_batch) {
     API_BEGIN
-    CHECK_PTR(eng);
+    CHECK_PTR(eng); LOCK_ENGINE(eng);
     if (mode < -1 || mode > 1) return fhe::fail("cluster mode: -1 (automatic), 0 (never) or 1 (always)");
     eng->impl->cluster_mode = mode;
     eng->impl->cluster_max_batch = max_batch;
@@ -141,7 +150,7 @@ int fhe_engine_set_cluster_mode(fhe_engine* eng, int mode, uint32_t max_batch) {
 
 int fhe_engine_cluster_info(fhe_engine* eng, uint32_t* clusters) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(clusters);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(clusters);
     if (eng->impl->synchronize()) return 1;
     *clusters = eng->impl->cluster_last;
     return 0;
@@ -150,7 +159,7 @@ int fhe_engine_cluster_info(fhe_engine* eng, uint32_t* clusters) {
 
 int fhe_lut_generate(fhe_engine* eng, const uint64_t* table, uint32_t* lut_id, uint64_t* degree) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(table); CHECK_PTR(lut_id);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(table); CHECK_PTR(lut_id);
     std::vector<uint64_t> acc;
     uint64_t deg = eng->impl->fill_accumulator(table, acc);
     if (degree) *degree = deg;
@@ -160,21 +169,21 @@ int fhe_lut_generate(fhe_engine* eng, const uint64_t* table, uint32_t* lut_id, u
 
 int fhe_lut_upload(fhe_engine* eng, const uint64_t* accumulator, uint32_t* lut_id) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(accumulator); CHECK_PTR(lut_id);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(accumulator); CHECK_PTR(lut_id);
     return eng->impl->lut_upload(accumulator, lut_id);
     API_END
 }
 
 int fhe_lut_download(fhe_engine* eng, uint32_t lut_id, uint64_t* accumulator) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(accumulator);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(accumulator);
     return eng->impl->lut_download(lut_id, accumulator);
     API_END
 }
 
 int fhe_lut_count(const fhe_engine* eng, uint32_t* count) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(count);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(count);
     *count = eng->impl->n_luts;
     return 0;
     API_END
@@ -182,7 +191,7 @@ int fhe_lut_count(const fhe_engine* eng, uint32_t* count) {
 
 int fhe_keyswitch_batch(fhe_engine* eng, const uint64_t* in, uint64_t* out, uint32_t count) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(in); CHECK_PTR(out);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(in); CHECK_PTR(out);
     return eng->impl->keyswitch_host(in, out, count);
     API_END
 }
@@ -190,7 +199,7 @@ int fhe_keyswitch_batch(fhe_engine* eng, const uint64_t* in, uint64_t* out, uint
 int fhe_pbs_batch(fhe_engine* eng, const uint64_t* in, const uint32_t* lut_idx, uint64_t* out,
                   uint32_t count) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(in); CHECK_PTR(out);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(in); CHECK_PTR(out);
     return eng->impl->pbs_host(in, lut_idx, out, count);
     API_END
 }
@@ -198,7 +207,7 @@ int fhe_pbs_batch(fhe_engine* eng, const uint64_t* in, const uint32_t* lut_idx, 
 int fhe_pbs_ks_batch(fhe_engine* eng, const uint64_t* in, const uint32_t* lut_idx, uint64_t* out,
                      uint32_t count) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(in); CHECK_PTR(out);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(in); CHECK_PTR(out);
     return eng->impl->pbs_ks_host(in, lut_idx, out, count);
     API_END
 }
@@ -206,7 +215,7 @@ int fhe_pbs_ks_batch(fhe_engine* eng, const uint64_t* in, const uint32_t* lut_id
 int fhe_ks_pbs_batch(fhe_engine* eng, const uint64_t* in, const uint32_t* lut_idx, uint64_t* out,
                      uint32_t count) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(in); CHECK_PTR(out);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(in); CHECK_PTR(out);
     return eng->impl->ks_pbs_host(in, lut_idx, out, count);
     API_END
 }
@@ -214,7 +223,7 @@ int fhe_ks_pbs_batch(fhe_engine* eng, const uint64_t* in, const uint32_t* lut_id
 int fhe_ks_pbs_batch_dev(fhe_engine* eng, const uint64_t* d_in, const uint32_t* d_lut_idx,
                          uint64_t* d_out, uint32_t count) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(d_in); CHECK_PTR(d_out);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(d_in); CHECK_PTR(d_out);
     return eng->impl->ks_pbs_dev(d_in, d_lut_idx, d_out, count, /*allow_pipeline=*/true);
     API_END
 }
@@ -223,7 +232,7 @@ int fhe_lwe_lincomb_batch(fhe_engine* eng, const uint64_t* pool, uint32_t pool_c
                           const uint32_t* off, const uint32_t* src, const int32_t* coeff,
                           const uint64_t* cst, uint64_t* out, uint32_t jobs) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(pool); CHECK_PTR(off); CHECK_PTR(src); CHECK_PTR(coeff);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(pool); CHECK_PTR(off); CHECK_PTR(src); CHECK_PTR(coeff);
     CHECK_PTR(cst); CHECK_PTR(out);
     return eng->impl->lincomb_host(pool, pool_count, off, src, coeff, cst, out, jobs);
     API_END
@@ -231,14 +240,14 @@ int fhe_lwe_lincomb_batch(fhe_engine* eng, const uint64_t* pool, uint32_t pool_c
 
 int fhe_last_kernel_ms(fhe_engine* eng, float ms[2]) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(ms);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(ms);
     return eng->impl->last_kernel_ms(ms);
     API_END
 }
 
 int fhe_kernel_times(fhe_engine* eng, double total_ms[2], uint32_t* calls, int reset) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(total_ms); CHECK_PTR(calls);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(total_ms); CHECK_PTR(calls);
     return eng->impl->kernel_times(total_ms, calls, reset != 0);
     API_END
 }
@@ -266,7 +275,7 @@ int fhe_plan_create(fhe_engine* eng, fhe_plan** out) {
     API_BEGIN
     CHECK_PTR(out);
     *out = nullptr;
-    CHECK_PTR(eng);
+    CHECK_PTR(eng); LOCK_ENGINE(eng);
     *out = new fhe_plan{new fhe::Circuit(eng->impl->p, eng->impl), false};
     return 0;
     API_END
@@ -284,14 +293,14 @@ int fhe_plan_create_offline(const fhe_params_t* params, fhe_plan** out) {
 
 int fhe_engine_set_stream(fhe_engine* eng, void* hip_stream) {
     API_BEGIN
-    CHECK_PTR(eng);
+    CHECK_PTR(eng); LOCK_ENGINE(eng);
     return eng->impl->set_stream((hipStream_t)hip_stream, false);
     API_END
 }
 
 int fhe_engine_reset_stream(fhe_engine* eng) {
     API_BEGIN
-    CHECK_PTR(eng);
+    CHECK_PTR(eng); LOCK_ENGINE(eng);
     return eng->impl->set_stream(nullptr, true);
     API_END
 }
@@ -299,7 +308,10 @@ int fhe_engine_reset_stream(fhe_engine* eng) {
 int fhe_plan_destroy(fhe_plan* p) {
     API_BEGIN
     if (!p) return 0;
-    delete p->c;
+    {
+        LOCK_PLAN(p);          // the circuit's destructor releases device memory of the engine's GPU
+        delete p->c;
+    }
     delete p;
     return 0;
     API_END
@@ -307,9 +319,11 @@ int fhe_plan_destroy(fhe_plan* p) {
 
 #define PLAN_BUILDING(p)                                   \
     CHECK_PTR(p);                                          \
+    LOCK_PLAN(p);                                          \
     if ((p)->finalized) return fail("plan already finalised")
 #define PLAN_READY(p)                                      \
     CHECK_PTR(p);                                          \
+    LOCK_PLAN(p);                                          \
     if (!(p)->finalized) return fail("plan not finalised")
 
 int fhe_plan_input(fhe_plan* p, uint64_t degree, uint32_t* node) {
@@ -414,7 +428,7 @@ int fhe_int_plan_create(fhe_engine* eng, const char* op, uint32_t n_blocks, uint
     API_BEGIN
     CHECK_PTR(out);
     *out = nullptr;
-    CHECK_PTR(eng); CHECK_PTR(op);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(op);
     return int_plan(eng->impl->p, eng->impl, op, n_blocks, scalar, world, out);
     API_END
 }
@@ -462,7 +476,7 @@ int fhe_str_plan_create(fhe_engine* eng, const char* op, uint32_t a_cap, uint32_
     API_BEGIN
     CHECK_PTR(out);
     *out = nullptr;
-    CHECK_PTR(eng); CHECK_PTR(op);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(op);
     return str_plan(eng->impl->p, eng->impl, op, a_cap, b_cap, clear, clear_len, world, out);
     API_END
 }
@@ -580,7 +594,7 @@ int fhe_plan_gather_outputs_dev(fhe_plan* p, const uint64_t* d_pool, uint64_t* d
 static int str_op_parts(fhe_engine* eng, const std::string& op, const uint64_t* const* operands, const uint32_t* caps,
                         uint32_t n_operands, const uint8_t* clear, uint32_t clear_len, uint64_t* out) {
     API_BEGIN
-    CHECK_PTR(eng); CHECK_PTR(out);
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(out);
     uint32_t a_cap = caps[0], b_cap = 0;
     for (uint32_t i = 0; i < n_operands; i++) {
         CHECK_PTR(operands[i]);

@@ -150,6 +150,7 @@ public:
     int run_host(const uint64_t* inputs, uint64_t* outputs);
     int run_host_parts(const uint64_t* const* parts, const uint32_t* counts, uint32_t n_parts, uint64_t* outputs);     // single GPU, host buffers
     ~Circuit();
+    Engine* engine() const { return eng_; }   // nullptr: offline plan
 
 private:
     void set_error(std::string e) { if (error_.empty()) error_ = std::move(e); }   // the first error is the cause

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -39,6 +40,7 @@ struct BrVariant;
 uint64_t fill_accumulator(const fhe_params_t& p, const uint64_t* table, std::vector<uint64_t>& acc);
 
 struct Engine {
+    std::recursive_mutex mu;      // taken by every C ABI entry point that touches this engine (c_api.cpp, LOCK_ENGINE)
     fhe_params_t p{};
     int device = 0;
     hipStream_t stream = nullptr;

@@ -17,9 +17,11 @@
  *   LUT / accumulator  [k+1][N] u64 (mask polynomials zero)
  *
  * Pointers named d_* are device (HBM) pointers on the engine's GPU; all others are host pointers.
- * An engine is bound to one GPU and one HIP stream; calls on one engine must be serialised by the
- * caller (the reference keeps its scratch in a thread-local ShortintEngine,
- * shortint/engine/mod.rs:23-25,184-189 -- here: one engine per host thread / per rank).
+ * An engine is bound to one GPU and one HIP stream.  Every entry point that touches an engine (directly or through
+ * one of its plans) takes that engine's lock, so several host threads may share one engine the way they share the
+ * reference's `Sync` ServerKey (shortint/engine/mod.rs:23-25,184-189 gives each thread its own scratch; here the
+ * calls are serialised instead: use one engine per thread or per rank for concurrency).  The asynchronous *_dev calls
+ * only enqueue work under the lock: ordering between threads is the callers' business, as with any shared stream.
  */
 #ifndef FHESTR_H
 #define FHESTR_H

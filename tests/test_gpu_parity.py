@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from conftest import gpu_engine, keyset, torus_distance
+from conftest import gpu_engine, keyset, to_fhestr_params, torus_distance
 
 pytestmark = pytest.mark.gpu
 
@@ -517,6 +517,48 @@ def test_pipelined_call_right_after_a_serial_one_and_stream_ordered_inputs(p22):
     assert all(np.array_equal(a, b) for a, b in zip(serial, piped))
     assert np.array_equal(serial[1], serial[2])
     assert np.array_equal(ks.ck.decrypt_many(piped[1].view(np.uint64))[:8], ks.ck.decrypt_many(serial[2].view(np.uint64))[:8])
+
+
+@pytest.mark.gpu
+def test_host_threads_share_one_engine(toy_k1):
+    """The reference's ServerKey is Sync (shortint/engine/mod.rs:23-25,184-189): several host threads may bootstrap with the
+    same key.  Here every C ABI entry point takes the engine's lock: four threads hammer one engine (host-buffer calls,
+    their own tables, a plan each) and every result decrypts right."""
+    import threading
+    import fhestr
+    ks = toy_k1
+    eng = gpu_engine(ks)
+    p = ks.params
+    M = p.msg_mod * p.carry_mod
+    errors = []
+
+    def worker(t):
+        try:
+            f = lambda x, t=t: (x + t) % M
+            lut, _ = eng.generate_lookup_table(f)
+            rng = np.random.default_rng(100 + t)
+            for it in range(6):
+                msgs = rng.integers(0, M, size=9 + t)
+                cts = ks.ck.encrypt_many(msgs, O.Rng(55 + t, it))
+                out = eng.apply_lookup_table(cts, np.full(len(msgs), lut, dtype=np.uint32))
+                if not np.array_equal(ks.ck.decrypt_many(out), np.array([f(int(m)) for m in msgs])):
+                    errors.append((t, it, "lut"))
+                assert np.array_equal(eng.keyswitch(cts), np.stack([ks.sk.keyswitch(c) for c in cts]))
+            plan = fhestr.Plan.string_op(eng, "eq", 4, 4)
+            a = ks.ck.encrypt_many(fhestr.string_to_blocks(to_fhestr_params(p), b"ab%dz" % t, 4), O.Rng(77 + t, 1))
+            res = plan.run(np.concatenate([a, a]))
+            if int(ks.ck.decrypt_many(res)[0]) != 1:
+                errors.append((t, "eq"))
+            plan.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
 
 
 @pytest.mark.gpu
