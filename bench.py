@@ -29,6 +29,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-leve
 # 157.3 TF FP32 vector rate (one wave64 f64 instruction occupies its SIMD for >= 4 cycles)
 F64_VALU_PEAK_TFLOPS = 78.6
 COUNTERS = os.path.join(ROOT, "profiles", "r03_counters.json")   # written by scripts/prof_round.py (round 3 kernels)
+COUNTERS_P44 = os.path.join(ROOT, "profiles", "r03_p44_counters.json")   # the same for `scripts/p44_prof.py 256` (config 5)
 SEED = 0x5EED0002
 
 
@@ -364,7 +365,7 @@ def bench_p44(fhestr, local_rank):
         # as is, separate --pmc passes) against the HBM peak; algorithmic bytes = the cluster's exchange matrices
         # (4 MB per LWE-step: 2 out + 2 back) + the 2 MB GGSW once per XCD and step
         try:
-            cj = json.load(open(COUNTERS))
+            cj = json.load(open(COUNTERS_P44))
             c = cj.get(out["kernel"])
             if c and c.get("batch") == B and cj.get("kernel_revision") == fhestr.kernel_revision():
                 steps = P.n
@@ -375,7 +376,7 @@ def bench_p44(fhestr, local_rank):
                                    "frac": algo / (br_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "traffic": c["traffic_bytes_per_launch"], "l2_hit_rate": c.get("l2_hit_rate"),
                                    "traffic_gbs": c["traffic_bytes_per_launch"] / (br_avg_ms * 1e-3) / 1e9,
-                                   "traffic_source": "profiles/r03_counters.json (static rocprofv3 --pmc passes, " + cj.get("p44_command", "") + ")"}
+                                   "traffic_source": "profiles/r03_p44_counters.json (static rocprofv3 --pmc passes, " + cj.get("p44_command", "") + ")"}
         except Exception:
             pass
         # config 5: 1024-char string, to_lower and replace (4-char clear pattern), one call each

@@ -10,9 +10,9 @@
 
 #include "../../include/fhestr.h"
 
-// bumped whenever a device kernel changes; profiles/r02_counters.json records the revision its
+// bumped whenever a device kernel changes; profiles/r03_counters.json records the revision its
 // rocprofv3 counters were taken on and bench.py only attaches them to a matching build
-#define FHESTR_KERNEL_REVISION "r02.5"
+#define FHESTR_KERNEL_REVISION "r03.1"
 
 namespace fhe {
 

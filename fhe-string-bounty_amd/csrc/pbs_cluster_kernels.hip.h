@@ -116,6 +116,52 @@ __device__ __forceinline__ uint64_t load_sc1_b64(RSRC rsrc, uint32_t voff) {
 // every cluster returns at once, the kernel drains with garbage and the host reports it (Engine::cluster_check).
 // PREFETCHED: vector-memory loads the caller issued AFTER its last store and wants to keep in flight across the
 // hand-over (vmcnt counts loads and stores together, in issue order: all but the youngest PREFETCHED are done).
+#ifndef FHESTR_CL_SYNC
+#define FHESTR_CL_SYNC 1
+#endif
+#if FHESTR_CL_SYNC == 1
+// No workgroup barrier anywhere in the hand-over: every wave drains its own stores, counts itself in on an LDS counter
+// (the wave that completes the count publishes the workgroup's epoch flag) and then polls the cluster's flag line
+// itself.  A wave that sees all C flags at this epoch knows that every wave of every member -- its own workgroup's
+// included -- has finished the phase, so the LDS planes may be reused as well.  The C flags of a cluster share one
+// 128-byte line (byte-masked stores into L2; one request per poll).
+template <int C, int PREFETCHED = 0>
+__device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, uint32_t& epoch, uint32_t* s_dead_generic,
+                                             ClusterCtl* ctl, ClusterStatus* status) {
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32_t;
+    lds_vu32_t* s_dead = (lds_vu32_t*)(uintptr_t)lds_address(s_dead_generic);
+    const uint32_t arrive_address = lds_address(s_dead_generic + 1);          // the arrival counter sits behind the dead word
+    constexpr uint32_t WAVES = 8;                                             // 512 threads
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PREFETCHED) : "memory");         // this wave's stores have reached L2
+    ++epoch;
+    if (*s_dead) return;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t before = 0;
+    if (lane == 0) {
+        const uint32_t one = 1;
+        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(before) : "v"(arrive_address), "v"(one) : "memory");
+    }
+    before = __builtin_amdgcn_readfirstlane(before);
+    if (before + 1 == WAVES * epoch && lane == 0)
+        __hip_atomic_store(flags + member, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint32_t spins = 0;
+    for (;;) {
+        const uint32_t v = lane < (uint32_t)C ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+        if (__all((int32_t)(v - epoch) >= 0)) break;
+        ++spins;
+        const bool others_gave_up = (spins & 1023u) == 0 && (*s_dead || __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (spins > CLUSTER_SPIN_LIMIT || others_gave_up) {
+            if (lane == 0) {
+                __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&status->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_dead = 1u;
+            }
+            break;
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+#else
 template <int C, int PREFETCHED = 0>
 __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, uint32_t& epoch, uint32_t* s_dead_generic,
                                              ClusterCtl* ctl, ClusterStatus* status) {
@@ -126,10 +172,10 @@ __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, u
     ++epoch;
     if (threadIdx.x < 64 && !*s_dead) {
         const uint32_t lane = threadIdx.x;
-        if (lane == 0) __hip_atomic_store(flags + member * 32, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_store(flags + member, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         uint32_t spins = 0;
         for (;;) {
-            const uint32_t v = lane < (uint32_t)C ? __hip_atomic_load(flags + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+            const uint32_t v = lane < (uint32_t)C ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
             if (__all((int32_t)(v - epoch) >= 0)) break;
             ++spins;
             const bool others_gave_up = (spins & 1023u) == 0 && __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -147,6 +193,8 @@ __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, u
     __syncthreads();
 }
 
+#endif
+
 template <int LOGN, int K1, int L>
 __global__ void __launch_bounds__((BrClusterCfg<LOGN, K1, L>::THREADS))
 blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
@@ -160,13 +208,15 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     __shared__ uint32_t s_form[4];
-    __shared__ uint32_t s_dead;
+    __shared__ uint32_t s_sync[2];        // [0] dead flag, [1] arrival counter of the hand-overs
+    uint32_t& s_dead = s_sync[0];
 
     const int tid = threadIdx.x;
 
     // ---- cluster formation (agent-scope atomics: valid wherever the workgroups landed) ----
     if (tid == 0) {
-        s_dead = 0;
+        s_sync[0] = 0;
+        s_sync[1] = 0;
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= 7u;

@@ -43,8 +43,9 @@ def run(cmd, log):
 
 
 def short(name):
-    for k in ("blind_rotate_seq_kernel", "blind_rotate_large_kernel", "blind_rotate_wide_kernel", "blind_rotate_multibit_kernel",
-              "blind_rotate_kernel", "keyswitch_dot4_kernel", "keyswitch_kernel", "lincomb_kernel"):
+    for k in ("blind_rotate_cluster_kernel", "blind_rotate_seq_kernel", "blind_rotate_large_kernel", "blind_rotate_wide_kernel",
+              "blind_rotate_multibit_kernel", "blind_rotate_kernel", "keyswitch_mfma_kernel", "ks_decompose_kernel",
+              "keyswitch_dot4_kernel", "keyswitch_kernel", "lincomb_kernel"):
         if k in name:
             return k
     return name[:60]
@@ -108,7 +109,7 @@ def main():
     res = {"_comment": "per-launch averages from rocprofv3 --pmc, one pass per counter set (scripts/prof_round.py); "
                        "traffic_bytes_per_launch = 2 x FETCH_SIZE (KB, gfx950 correction for 16-B/lane streaming "
                        "loads, MI355X_MICROARCH.md 'HBM') + WRITE_SIZE (KB); fabric-side bytes incl. Infinity-Cache hits",
-           "kernel_revision": rev, "command": " ".join(prog)}
+           "kernel_revision": rev, "command": " ".join(prog), "p44_command": " ".join(prog) if p44 else ""}
     for k, d in per_kernel.items():
         e = dict(d)
         e["batch"] = 256
@@ -120,7 +121,7 @@ def main():
     with open(os.path.join(out, f"{tag}_counters.json"), "w") as f:
         json.dump(res, f, indent=1)
     print(open(os.path.join(out, f"{tag}_kernel_stats.csv")).read()[:1500])
-    print(json.dumps({k: v for k, v in res.items() if k.startswith("blind")}, indent=1)[:3000])
+    print(json.dumps({k: v for k, v in res.items() if k.startswith(("blind", "keyswitch"))}, indent=1)[:4000])
 
 
 if __name__ == "__main__":
