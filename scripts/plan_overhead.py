@@ -10,9 +10,11 @@ eng = fhestr.Engine(P, 0); eng.generate_keys(g, s, 1)
 rng = np.random.default_rng(0)
 hay = bytes(rng.integers(0x61, 0x7B, size=256, dtype=np.uint8))
 enc = lambda t, cap: ck.encrypt(fhestr.string_to_blocks(P, t, cap))
-for op, bcap, second in (("eq", 256, hay), ("contains", 16, hay[100:116])):
-    plan = fhestr.Plan.string_op(eng, op, 256, bcap)
-    inputs = np.concatenate([enc(hay, 256), enc(second, bcap)])
+text = bytes(rng.integers(0x41, 0x7B, size=1000, dtype=np.uint8))
+for op, acap, bcap, second in (("eq", 256, 256, hay), ("contains", 256, 16, hay[100:116]), ("to_lower", 1024, 0, None)):
+    plan = fhestr.Plan.string_op(eng, op, acap, bcap)
+    inputs = np.concatenate([enc(hay, 256), enc(second, bcap)]) if second is not None else enc(text, 1024)
+    print(op, "levels:", [plan.level_info(l)["local_size"] for l in range(plan.info()["n_levels"])])
     info = plan.info()
     plan.run(inputs)
     eng.synchronize(); eng.kernel_times(reset=True)
