@@ -782,13 +782,15 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
         }
         return 0;
     }
-    if (v->cluster_fn && cluster_mode != 0 && (cluster_mode == 1 || count <= cluster_max_batch)) {
+    // (a device with fewer than 8 * C compute units -- e.g. one XCD of a partitioned GPU -- cannot host a grid of the
+    // cluster kernel: it takes the one-workgroup kernel below)
+    if (v->cluster_fn && cluster_mode != 0 && (cluster_mode == 1 || count <= cluster_max_batch) &&
+        (uint32_t)cu_count >= 8u * (uint32_t)v->cluster_size) {
         // Several CUs per LWE: the grid is a whole number of 8 * C workgroups (the dispatcher deals workgroups
         // round-robin over the 8 XCDs, the kernel forms its clusters from what each XCD actually received),
         // never more than one workgroup per CU -- every workgroup of the grid must be resident at once.
         const uint32_t C = (uint32_t)v->cluster_size, quantum = 8 * C;
         const uint32_t max_clusters = std::min<uint32_t>((uint32_t)CLUSTER_MAX, ((uint32_t)cu_count / quantum) * 8);
-        if (max_clusters == 0) return fail("cluster kernel: device has fewer than 8 * C compute units");
         const uint32_t want = std::min(count, max_clusters);
         const uint32_t grid = (want + 7) / 8 * quantum;
         if (ensure(&d_cluster_ws, &cap_cluster_ws, (size_t)max_clusters * v->cluster_ws)) return 1;
