@@ -77,6 +77,16 @@ def cpu_baseline(P, bsk, ksk, cts, lut_tables, lut_sel):
         candidates = [max(1, int(os.environ["FHESTR_CPU_BASELINE_THREADS"]))]
     else:
         candidates = sorted({c for c in (16, 32, 64, 128, int(quota) if quota else 0, affinity, nproc) if 1 <= c <= nproc})
+    try:   # rebuild the checker for this host's ISA (AVX-512 where present); falls back to the shipped build
+        O.build(force=True, arch="native")
+    except Exception:
+        pass
+    L = O.lib()
+    fbsk = np.zeros(bsk.size, dtype=np.float64)
+    L.orc_bsk_to_fourier(C.byref(op.c()), bsk, fbsk)
+    luts = np.zeros((len(lut_tables), op.glwe_len), dtype=np.uint64)
+    for i, t in enumerate(lut_tables):
+        L.orc_fill_accumulator(C.byref(op.c()), np.ascontiguousarray(t, dtype=np.uint64), luts[i])
     n_batch = cts.shape[0]
     idx_batch = np.ascontiguousarray(np.asarray(lut_sel, dtype=np.uint32))
     scan = {}
