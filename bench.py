@@ -262,20 +262,20 @@ def flop_per_cmux_step(P):
     return ffts * 5 * half * (half.bit_length() - 1) + 8 * L * k1 * k1 * half + 6 * half * ffts
 
 
-def rooflines(P, B, world, value, br_avg_ms, revision, log2_points):
+def rooflines(P, B, world, value, br_avg_ms, revision, log2_points, kernel="blind_rotate_kernel", concurrency=1):
     """The `roofline` object of the bench contract (HBM, SURVEY 8(d)'s per-LWE key-streaming model for the
     dominant kernel) and, next to it, what actually bounds that kernel: f64 VALU issue + LDS
     (`roofline`; SURVEY's model is `roofline_hbm_model`).  Counter-derived fields come from the committed rocprofv3 passes
     (profiles/r03_counters.json, one --pmc pass per counter set, scripts/prof_round.py) and are only
     attached when they were taken on this kernel revision, batch and variant."""
     br_bytes = P.bsk_len * 8 + P.glwe_len * 8 + P.small_size * 8 + P.big_size * 8   # BSK + LUT + LWE in/out
-    achieved = br_bytes * B / (br_avg_ms * 1e-3) / 1e9
+    achieved = concurrency * br_bytes * B / (br_avg_ms * 1e-3) / 1e9
     pbs_bytes = P.bsk_len * 8 + P.ksk_len * 8 + 2 * P.big_size * 8 + P.glwe_len * 8  # 109,559,824 (P22)
     compulsory = (P.bsk_len * 8 + P.ksk_len * 8) / B + 2 * P.big_size * 8 + P.small_size * 16
     ctr, src = None, None
     try:
         cj = json.load(open(COUNTERS))
-        c = cj["blind_rotate_kernel"]
+        c = cj[kernel]
         if c["batch"] == B and log2_points == 0 and cj.get("kernel_revision") == revision:
             ctr, src = c, "profiles/r03_counters.json (static: rocprofv3 --pmc passes of this kernel revision, " + cj.get("command", "") + ")"
     except Exception:
@@ -283,7 +283,7 @@ def rooflines(P, B, world, value, br_avg_ms, revision, log2_points):
     traffic = ctr["traffic_bytes_per_launch"] if ctr else None
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
-            "kernel": "blind_rotate_kernel", "avg_launch_ms": br_avg_ms,
+            "kernel": kernel, "avg_launch_ms": br_avg_ms,
             "algorithmic_bytes_per_lwe": br_bytes, "lwes_per_launch": B,
             "model": "per-LWE key streaming (SURVEY 8(d)): every LWE is charged the whole Fourier key",
             "note": "NOT the binding resource: the 48.6 MB key is shared by all workgroups and served from "
@@ -294,10 +294,11 @@ def rooflines(P, B, world, value, br_avg_ms, revision, log2_points):
         roof["l2_hit_rate"] = ctr.get("l2_hit_rate")
     flop_step = flop_per_cmux_step(P)
     n_steps = P.n if P.grouping <= 1 else P.n // P.grouping
-    tflops = B * n_steps * flop_step / (br_avg_ms * 1e-3) / 1e12
+    # `concurrency` launches of this kernel share the GPU (overlapped-batches mode: 2), each lasting br_avg_ms
+    tflops = concurrency * B * n_steps * flop_step / (br_avg_ms * 1e-3) / 1e12
     comp = {"bound": "valu_f64", "achieved": tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": tflops / F64_VALU_PEAK_TFLOPS, "flop_per_cmux_step": flop_step, "cmux_steps": n_steps,
-            "kernel": "blind_rotate_kernel",
+            "kernel": kernel, "launches_sharing_the_gpu": concurrency,
             "model": "algorithmic f64 FLOP (5 n log2 n per FFT) / launch time vs the FP64 vector peak"}
     if ctr and "SQ_BUSY_CYCLES" in ctr:
         # SQ_BUSY_CYCLES is summed over the 32 shader engines; SQ_ACTIVE_INST_* / SQ_WAIT_* count
@@ -476,11 +477,16 @@ def main():
 
     d_in = torch.from_numpy(cts.view(np.int64)).cuda()
     d_idx = torch.from_numpy(idx.view(np.int32)).cuda()
-    d_out = torch.zeros_like(d_in)
+    # independent batches write to their own buffers (a ring of four): calls that write the same buffer are ordered by
+    # the engine, which would serialise the overlapped mode
+    d_outs = [torch.zeros_like(d_in) for _ in range(4)]
+    d_out = d_outs[0]
     torch.cuda.synchronize()
+    step_no = [0]
 
     def step():
-        eng.apply_lookup_table_dev(d_in.data_ptr(), d_idx.data_ptr(), d_out.data_ptr(), B)
+        eng.apply_lookup_table_dev(d_in.data_ptr(), d_idx.data_ptr(), d_outs[step_no[0] & 3].data_ptr(), B)
+        step_no[0] += 1
 
     def fence():
         eng.synchronize()
@@ -490,7 +496,10 @@ def main():
 
     # throughput mode: consecutive steps are independent batches, so the keyswitch of step k+1 may run in the shadow
     # of the blind rotation of step k (fhe_engine_set_pipeline); the serial figure is reported next to it
-    eng.set_pipeline(not args.serial)
+    # Headline = overlapped batches (mode 2: consecutive steps alternate between two streams on the two-LWEs-per-CU
+    # kernel); mode 1 (keyswitch in the shadow of the previous blind rotation, the round-2 headline) and the serial
+    # figure are reported next to it.
+    eng.set_pipeline(0 if args.serial else 2)
     for _ in range(args.warmup):
         step()
     fence()
@@ -503,7 +512,27 @@ def main():
     elapsed = time.perf_counter() - t0
     ks_ms, br_ms, calls = eng.kernel_times(reset=True)
     eng.set_pipeline(False)
-    got = d_out.cpu().numpy().view(np.uint64).copy()      # the TIMED loop's output, before anything else writes
+    got = d_out.cpu().numpy().view(np.uint64).copy()      # the TIMED loop's outputs, before anything else writes
+    got_others = [d.cpu().numpy().view(np.uint64).copy() for d in d_outs[1:]]
+    shadow = None
+    if not args.serial:        # mode 1: only the keyswitch overlaps (bit-identical to serial calls)
+        eng.set_pipeline(1)
+        n_sh = min(args.steps, 20)
+        d_out_sh = torch.zeros_like(d_in)
+        for _ in range(3):
+            eng.apply_lookup_table_dev(d_in.data_ptr(), d_idx.data_ptr(), d_out_sh.data_ptr(), B)
+        eng.synchronize()
+        eng.kernel_times(reset=True)
+        t1 = time.perf_counter()
+        for _ in range(n_sh):
+            eng.apply_lookup_table_dev(d_in.data_ptr(), d_idx.data_ptr(), d_out_sh.data_ptr(), B)
+        eng.synchronize()
+        sh_dt = (time.perf_counter() - t1) / n_sh
+        sh_ks, sh_br, sh_calls = eng.kernel_times(reset=True)
+        eng.set_pipeline(0)
+        shadow = {"ms_per_step": sh_dt * 1e3, "pbs_per_s_per_gpu": B / sh_dt,
+                  "verified_decrypt": bool(np.array_equal(ck.decrypt(d_out_sh.cpu().numpy().view(np.uint64)), tables[sel, msgs])),
+                  "kernel_ms": {"keyswitch": sh_ks / max(sh_calls, 1), "blind_rotate": sh_br / max(sh_calls, 1)}}
     serial = None
     if not args.serial:        # the same steps one after the other (what a single dependent chain of calls gets)
         n_serial = min(args.steps, 10)
@@ -535,7 +564,7 @@ def main():
 
     # ---- correctness gate on the timed (pipelined unless --serial) output: decrypt == LUT(message) for every LWE ----
     dec = ck.decrypt(got)
-    verified = bool(np.array_equal(dec, tables[sel, msgs]))
+    verified = bool(np.array_equal(dec, tables[sel, msgs])) and all(bool(np.array_equal(ck.decrypt(g), tables[sel, msgs])) for g in got_others)
     if world > 1:
         v = torch.tensor([1 if verified else 0], device=coll_dev)
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
@@ -596,8 +625,10 @@ def main():
             "kernel_ms": {"keyswitch": ks_ms / max(calls, 1), "blind_rotate": br_avg_ms, "launches": calls,
                           "kernel_revision": fhestr.kernel_revision()},
             "pipelined": (None if args.serial else
-                          "keyswitch of step k+1 on a second stream, co-resident with the blind rotation of step k "
-                          "(fhe_engine_set_pipeline); kernel_ms.keyswitch is that 64-register variant's duration while sharing the CUs"),
+                          "overlapped batches (fhe_engine_set_pipeline(2)): consecutive steps alternate between two streams on the "
+                          "two-LWEs-per-CU kernel, two batches share the GPU; kernel_ms are the durations of kernels that overlap, "
+                          "ms_per_step is wall time / steps"),
+            "pipelined_keyswitch_only": shadow,
             "serial": serial,
             # every rank's own rate over the same timed steps: value = the sum of the batches / the slowest rank's time
             "per_rank_pbs_per_s": [B * args.steps / e for e in per_rank_elapsed],
@@ -608,13 +639,16 @@ def main():
             "shared_identity_lut": identity,
             "batch_sweep_pbs_per_s": sweep,
         }
-        rec.update(rooflines(P, B, world, value, br_avg_ms, fhestr.kernel_revision(), args.log2_points))
-        if serial:   # the same kernel when nothing shares the CUs with it (the serial comparison steps)
+        overlapped = not args.serial
+        rec.update(rooflines(P, B, world, value, br_avg_ms, fhestr.kernel_revision(), args.log2_points,
+                             kernel="blind_rotate_wide_kernel" if overlapped else "blind_rotate_kernel", concurrency=2 if overlapped else 1))
+        if serial:   # the one-LWE-per-CU kernel of the serial comparison steps, nothing sharing the CUs with it
             alone = rooflines(P, B, world, value, serial["kernel_ms"]["blind_rotate"], fhestr.kernel_revision(), args.log2_points)
             rec["roofline"]["kernel_alone"] = {"avg_launch_ms": serial["kernel_ms"]["blind_rotate"], "frac": alone["roofline"]["frac"]}
             rec["roofline_hbm_model"]["kernel_alone"] = {"avg_launch_ms": serial["kernel_ms"]["blind_rotate"],
                                                          "frac": alone["roofline_hbm_model"]["frac"]}
-            rec["roofline"]["note"] = "avg_launch_ms is measured with the next step's keyswitch co-resident (pipelined mode), kernel_alone without"
+            rec["roofline"]["note"] = ("overlapped batches: two launches of the two-LWEs-per-CU kernel share the GPU, avg_launch_ms is one launch's "
+                                       "duration; kernel_alone = the one-LWE-per-CU kernel of the serial steps")
 
 
     # ---- FheString ms/op (BASELINE.json configs 3 and 4): level batches sharded over the ranks, one

@@ -116,7 +116,8 @@ int fhe_engine_set_pipeline(fhe_engine* eng, int on) {
     API_BEGIN
     CHECK_PTR(eng); LOCK_ENGINE(eng);
     if (eng->impl->synchronize()) return 1;
-    eng->impl->pipeline = on != 0;
+    if (on < 0 || on > 2) return fhe::fail("pipeline mode: 0 (off), 1 (keyswitch in the shadow of the previous blind rotation) or 2 (overlapped batches)");
+    eng->impl->pipeline = on;
     return 0;
     API_END
 }

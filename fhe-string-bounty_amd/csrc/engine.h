@@ -52,12 +52,26 @@ struct Engine {
     const BrVariant* variant = nullptr;       // layout used up to one LWE per CU
     const BrVariant* variant_large = nullptr; // same Fourier-key layout, used for larger batches (may equal variant)
     int cu_count = 256;
-    bool pipeline = false;                    // ks_pbs_dev: keyswitch of call k+1 in the shadow of the blind rotation of call k
+    int pipeline = 0;                         // ks_pbs_dev throughput modes: 1 = keyswitch of call k+1 in the shadow of the blind rotation of call k; 2 = whole calls overlapped on two streams
     hipStream_t ks_stream = nullptr;
     hipEvent_t pipe_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // keyswitch done [slot], blind rotation done [slot], engine stream so far
     hipEvent_t pipe_input_ready = nullptr;    // caller's event the next pipelined keyswitch waits for (one shot)
     const void* pipe_out[2] = {nullptr, nullptr};
     size_t pipe_out_bytes[2] = {0, 0};
+    // mode 2 (overlapped batches): calls rotate over ovl_streams streams (slot 0 = the engine stream, 1 = ks_stream)
+    static constexpr int OVL_MAX = 4;
+    int ovl_streams = 3;
+    hipStream_t ovl_stream[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ovl_done[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};
+    const void* ovl_in[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};
+    const void* ovl_out[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};
+    size_t ovl_bytes[OVL_MAX] = {0, 0, 0, 0};
+    uint64_t* ovl_small[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};      // small-ciphertext buffer per stream
+    size_t ovl_cap_small[OVL_MAX] = {0, 0, 0, 0};
+    int8_t* ovl_digits[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};       // keyswitch digit fragments per stream (slot 0: d_ks_digits)
+    size_t ovl_cap_digits[OVL_MAX] = {0, 0, 0, 0};
+    int sync_all_streams();
+    void end_pipeline_run();
     uint64_t pipe_calls = 0;
     int shadow_fit = -1;                      // -1 unknown, else whether a 64-VGPR wave fits next to the rotation's
     uint32_t multibit_combine_max = 64;       // multi-bit PBS: batches up to this size prepare their GGSWs on the whole GPU first
@@ -114,8 +128,8 @@ struct Engine {
     int ensure_batch(uint32_t count);
     int check_lut_idx(const uint32_t* lut_idx, uint32_t count) const;
 
-    int launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t count, hipStream_t on = nullptr, bool shadow = false);
-    int launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx, uint64_t* d_big, uint32_t count);
+    int launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t count, hipStream_t on = nullptr, bool shadow = false, int digits_slot = 0);
+    int launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx, uint64_t* d_big, uint32_t count, hipStream_t on = nullptr, bool two_per_cu = false);
     bool shadow_keyswitch_fits();
     int ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint64_t* d_big_out, uint32_t count, bool allow_pipeline = false);
     int ks_pbs_host(const uint64_t* in, const uint32_t* lut_idx, uint64_t* out, uint32_t count);

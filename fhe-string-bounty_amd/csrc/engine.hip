@@ -271,6 +271,7 @@ int Engine::create(const fhe_params_t& p, int device, Engine** out) {
     e->device = device;
     e->variant = v;
     e->variant_large = v;
+    if (const char* m = getenv("FHESTR_OVERLAP_STREAMS")) e->ovl_streams = std::min((int)Engine::OVL_MAX, std::max(2, atoi(m)));
     if (const char* m = getenv("FHESTR_KS_MFMA")) e->ks_mfma_enabled = atoi(m) != 0;
     if (const char* m = getenv("FHESTR_CLUSTER")) e->cluster_mode = std::min(1, std::max(-1, atoi(m)));
     if (const char* m = getenv("FHESTR_MULTIBIT_COMBINE_MAX")) e->multibit_combine_max = (uint32_t)std::min(1024, std::max(0, atoi(m)));
@@ -294,6 +295,7 @@ Engine::~Engine() {
     auto rel = [](void* ptr) { if (ptr) (void)hipFree(ptr); };
     rel(d_ksk); rel(d_ksk_packed); rel(d_ksk_rowsum); rel(d_fbsk); rel(d_luts); rel(d_in); rel(d_small); rel(d_small2); rel(d_out); rel(d_idx);
     rel(d_pool); rel(d_meta); rel(d_ws); rel(d_slot_exp); rel(d_cluster_ws); rel(d_cluster_ctl); rel(d_ksk_mfma); rel(d_ks_digits);
+    for (int q = 0; q < OVL_MAX; q++) { rel(ovl_digits[q]); rel(ovl_small[q]); if (ovl_done[q]) (void)hipEventDestroy(ovl_done[q]); if (q >= 2 && ovl_stream[q]) (void)hipStreamDestroy(ovl_stream[q]); }
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ring) if (e) (void)hipEventDestroy(e);
     for (auto& e : pipe_ev) if (e) (void)hipEventDestroy(e);
@@ -649,7 +651,7 @@ int Engine::ensure_batch(uint32_t count) {
     return 0;
 }
 
-int Engine::launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t count, hipStream_t on, bool shadow) {
+int Engine::launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t count, hipStream_t on, bool shadow, int digits_slot) {
     if (!d_ksk && !d_ksk_packed) return fail("keys not loaded");
     hipStream_t s = on ? on : stream;
     // grid.y = sample tiles; HIP caps grid.y at 65535
@@ -661,14 +663,16 @@ int Engine::launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t cou
         const KsMfmaGeom g = ks_mfma_geom(in_dim, out_size, p.ks_level, p.ks_base_log);
         const uint32_t row_tiles = (count + 31) / 32;
         const size_t need = (size_t)row_tiles * g.steps * 1024;
-        if (need > cap_ks_digits) {
-            if (d_ks_digits) { HIP_TRY(hipStreamSynchronize(stream)); if (ks_stream) HIP_TRY(hipStreamSynchronize(ks_stream)); HIP_TRY(hipFree(d_ks_digits)); }
-            d_ks_digits = nullptr; cap_ks_digits = 0;
-            HIP_TRY(hipMalloc((void**)&d_ks_digits, need));
-            HIP_TRY(hipMemsetAsync(d_ks_digits, 0, need, s));      // the pad slots stay zero for the buffer's lifetime
-            cap_ks_digits = need;
+        int8_t*& digits = digits_slot ? ovl_digits[digits_slot] : d_ks_digits;     // own buffer per overlapped stream
+        size_t& cap_digits = digits_slot ? ovl_cap_digits[digits_slot] : cap_ks_digits;
+        if (need > cap_digits) {
+            if (digits) { if (sync_all_streams()) return 1; HIP_TRY(hipFree(digits)); }
+            digits = nullptr; cap_digits = 0;
+            HIP_TRY(hipMalloc((void**)&digits, need));
+            HIP_TRY(hipMemsetAsync(digits, 0, need, s));
+            cap_digits = need;
         }
-        KsDecomposeArgs da{d_big, d_ks_digits, g, count};
+        KsDecomposeArgs da{d_big, digits, g, count};
         hipLaunchKernelGGL(ks_decompose_kernel, dim3((2 * g.steps + 255) / 256, count), dim3(256), 0, s, da);
         uint32_t mt = 1;
         while (mt < 8 && mt < row_tiles) mt *= 2;
@@ -681,7 +685,7 @@ int Engine::launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t cou
         chunks = std::max(1u, std::min(chunks, (g.steps + 7) / 8));
         const uint32_t spc = (g.steps + chunks - 1) / chunks;
         chunks = (g.steps + spc - 1) / spc;
-        KsMfmaArgs ma{d_big, d_ksk_mfma, d_ks_digits, d_sm, g, count, row_tiles, spc};
+        KsMfmaArgs ma{d_big, d_ksk_mfma, digits, d_sm, g, count, row_tiles, spc};
         const dim3 grid(g.col_groups, gy, chunks);
         switch (mt) {
             case 1: hipLaunchKernelGGL(keyswitch_mfma_kernel<1>, grid, dim3(64), 0, s, ma); break;
@@ -715,11 +719,16 @@ int Engine::launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t cou
 }
 
 int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx, uint64_t* d_big,
-                                uint32_t count) {
+                                uint32_t count, hipStream_t on, bool two_per_cu) {
     if (!d_fbsk) return fail("keys not loaded");
     if (n_luts == 0) return fail("no lookup table uploaded");
     BlindRotateArgs a{d_sm, d_lut_idx, d_luts, d_fbsk, d_big, p.n, p.pbs_base_log, count};
     void* args[] = {(void*)&a};
+    if (two_per_cu) {          // overlapped throughput mode: the compact layout whatever the batch size, on the given stream
+        const BrVariant* w = variant_large;
+        HIP_TRY(hipLaunchKernel(w->rotate_fn, dim3(count), dim3(w->threads), args, w->lds_bytes + (size_t)p.n * w->lds_per_n, on ? on : stream));
+        return 0;
+    }
     // one LWE per CU or fewer: spread it over more threads; above that: the compact layout that
     // lets two LWEs share a CU
     const BrVariant* v = count > (uint32_t)cu_count ? variant_large : variant;
@@ -849,7 +858,63 @@ int Engine::ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint
     }
     hipEvent_t* e4 = &ring[(ring_used % RING) * 4];     // keyswitch start / end, blind rotation start / end
     ring_used++;
-    if (allow_pipeline && pipeline && stream == own_stream && !variant->large && !variant->wide && !variant->extprod_fn &&
+    if (allow_pipeline && pipeline == 2 && stream == own_stream && variant_large != variant && variant_large->wide &&
+        !variant->extprod_fn && !variant->combine_fn && count <= (uint32_t)cu_count) {
+        // Overlapped batches (fhe_engine_set_pipeline(2)): consecutive calls rotate over OVL_STREAMS streams and run on the
+        // two-LWEs-per-CU kernel.  Two launches fill the GPU, the third queues behind them and its workgroups take the
+        // slots the oldest launch frees one by one -- the GPU stays full like inside one 4,096-LWE launch (121 k PBS/s)
+        // although every batch has 256 LWEs; the price is each call's latency.  Same ordering rules as mode 1, plus
+        // write-after-write / write-after-read against the calls still in flight on the other streams.  Results are
+        // those of the large-batch kernel.
+        const int ns = ovl_streams;
+        if (!ks_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&ks_stream, hipStreamNonBlocking));
+            for (auto& e : pipe_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        for (int q = 2; q < ns; q++)
+            if (!ovl_stream[q]) {
+                HIP_TRY(hipStreamCreateWithFlags(&ovl_stream[q], hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&ovl_done[q], hipEventDisableTiming));
+            }
+        for (int q = 0; q < 2; q++)
+            if (!ovl_done[q]) HIP_TRY(hipEventCreateWithFlags(&ovl_done[q], hipEventDisableTiming));
+        const int slot = (int)(pipe_calls % (uint64_t)ns);
+        hipStream_t s = slot == 0 ? stream : slot == 1 ? ks_stream : ovl_stream[slot];
+        if (ensure((void**)&ovl_small[slot], &ovl_cap_small[slot], count * small * 8)) return 1;
+        uint64_t* sm = ovl_small[slot];
+        const size_t big = (size_t)p.k * p.N + 1;
+        const char *in_lo = (const char*)d_big_in, *in_hi = in_lo + (size_t)count * big * 8;
+        const char *out_lo = (const char*)d_big_out, *out_hi = out_lo + (size_t)count * big * 8;
+        if (pipe_calls == 0) HIP_TRY(hipEventRecord(pipe_ev[4], stream));       // what the engine stream held before this run
+        if (pipe_calls < (uint64_t)ns && slot != 0) HIP_TRY(hipStreamWaitEvent(s, pipe_ev[4], 0));
+        if (pipe_input_ready) {
+            HIP_TRY(hipStreamWaitEvent(s, pipe_input_ready, 0));
+            pipe_input_ready = nullptr;
+        }
+        auto overlaps = [](const char* a_lo, const char* a_hi, const void* b, size_t b_bytes) {
+            const char* b_lo = (const char*)b;
+            return b_lo && a_lo < b_lo + b_bytes && b_lo < a_hi;
+        };
+        for (int q = 0; q < ns; q++) {       // calls possibly still in flight on the other streams
+            if (q == slot || !ovl_out[q]) continue;
+            if (overlaps(in_lo, in_hi, ovl_out[q], ovl_bytes[q]) || overlaps(out_lo, out_hi, ovl_out[q], ovl_bytes[q]) ||
+                overlaps(out_lo, out_hi, ovl_in[q], ovl_bytes[q]))
+                HIP_TRY(hipStreamWaitEvent(s, ovl_done[q], 0));
+        }
+        ovl_in[slot] = d_big_in;
+        ovl_out[slot] = d_big_out;
+        ovl_bytes[slot] = (size_t)count * big * 8;
+        HIP_TRY(hipEventRecord(e4[0], s));
+        if (launch_keyswitch(d_big_in, sm, count, s, false, slot)) return 1;
+        HIP_TRY(hipEventRecord(e4[1], s));
+        HIP_TRY(hipEventRecord(e4[2], s));
+        if (launch_blind_rotate(sm, d_lut_idx, d_big_out, count, s, true)) return 1;
+        HIP_TRY(hipEventRecord(e4[3], s));
+        HIP_TRY(hipEventRecord(ovl_done[slot], s));
+        pipe_calls++;
+        return 0;
+    }
+    if (allow_pipeline && pipeline == 1 && stream == own_stream && !variant->large && !variant->wide && !variant->extprod_fn &&
         count <= (uint32_t)cu_count && shadow_keyswitch_fits()) {
         // Pipelined mode (fhe_engine_set_pipeline): the keyswitch of this call runs on a second stream, in a 64-VGPR
         // variant whose waves fit next to the two 220-VGPR waves per SIMD of the blind rotation still running for the
@@ -892,10 +957,10 @@ int Engine::ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint
         pipe_calls++;
         return 0;
     }
-    if (ks_stream && pipe_calls) {        // a serial call after pipelined ones: the shadow keyswitches must be done with d_small
+    if (ks_stream && pipe_calls) {        // a serial call after pipelined ones: the other streams must be done with the shared buffers
         HIP_TRY(hipStreamSynchronize(ks_stream));
-        pipe_calls = 0;
-        pipe_out[0] = pipe_out[1] = nullptr;
+        for (int q = 2; q < OVL_MAX; q++) if (ovl_stream[q]) HIP_TRY(hipStreamSynchronize(ovl_stream[q]));
+        end_pipeline_run();
     }
     pipe_input_ready = nullptr;           // serial calls are stream-ordered: nothing to wait for
     HIP_TRY(hipEventRecord(e4[0], stream));
@@ -1050,11 +1115,22 @@ extern "C" int fhe_debug_read_stamps(unsigned long long* out, size_t count) {
 
 int Engine::synchronize() {
     if (use()) return 1;
-    if (ks_stream) HIP_TRY(hipStreamSynchronize(ks_stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    pipe_calls = 0;                       // both streams are idle: the next pipelined call starts a new run
-    pipe_out[0] = pipe_out[1] = nullptr;
+    if (sync_all_streams()) return 1;
+    end_pipeline_run();                   // every stream is idle: the next pipelined call starts a new run
     return cluster_check();
+}
+
+int Engine::sync_all_streams() {
+    if (ks_stream) HIP_TRY(hipStreamSynchronize(ks_stream));
+    for (int q = 2; q < OVL_MAX; q++) if (ovl_stream[q]) HIP_TRY(hipStreamSynchronize(ovl_stream[q]));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
+void Engine::end_pipeline_run() {
+    pipe_calls = 0;
+    pipe_out[0] = pipe_out[1] = nullptr;
+    for (int q = 0; q < OVL_MAX; q++) ovl_in[q] = ovl_out[q] = nullptr;
 }
 
 // The cluster kernel never hangs on a hand-over that does not arrive: it gives up, finishes with garbage and says so

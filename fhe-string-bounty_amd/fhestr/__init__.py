@@ -369,10 +369,16 @@ class Engine:
                                                   C.c_void_p(d_out) if d_out else None, _ptr(out) if out is not None else None))
         return out
 
-    def set_pipeline(self, on: bool):
-        """Throughput mode for back-to-back apply_lookup_table_dev calls: the keyswitch of call k+1 runs in the shadow
-        of the blind rotation of call k (include/fhestr.h, fhe_engine_set_pipeline)."""
-        _check(lib().fhe_engine_set_pipeline(self._h, int(bool(on))))
+    def set_variant(self, selector: int):
+        """Blind-rotation variant: log2(points per thread), + 16 for the two-LWEs-per-CU layout; 0 = automatic.  After the
+        keys are loaded only variants with the same points per thread (same Fourier key layout) can be chosen."""
+        _check(lib().fhe_engine_set_variant(self._h, selector))
+
+    def set_pipeline(self, mode):
+        """Throughput modes for back-to-back apply_lookup_table_dev calls (include/fhestr.h, fhe_engine_set_pipeline):
+        0 / False off; 1 / True the keyswitch of call k+1 in the shadow of the blind rotation of call k; 2 whole calls
+        overlapped on two streams on the two-LWEs-per-CU kernel."""
+        _check(lib().fhe_engine_set_pipeline(self._h, int(mode)))
 
     def pipeline_input_event(self, hip_event: int):
         """The next pipelined apply_lookup_table_dev call's keyswitch waits for this hipEvent_t (e.g.

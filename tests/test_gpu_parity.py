@@ -470,6 +470,56 @@ def test_pipelined_calls_are_bit_identical_to_serial_ones(p22):
 
 
 @pytest.mark.gpu
+def test_overlapped_batches_mode_matches_the_large_batch_kernel(p22):
+    """fhe_engine_set_pipeline(2): consecutive 96-LWE calls alternate between two streams on the two-LWEs-per-CU kernel.
+    Independent batches, a chain (every call reads the previous call's output), one buffer written by every call and a
+    call that overwrites the previous call's input: bit-identical to the same calls made one after the other on that
+    kernel (variant selector 16 | 2), decrypt-identical to the default serial path."""
+    import torch
+    ks = p22
+    eng = gpu_engine(ks)
+    p = ks.params
+    M = p.msg_mod * p.carry_mod
+    lut, _ = eng.generate_lookup_table(lambda x: (7 * x + 1) % M)
+    rng = np.random.default_rng(29)
+    B = 96
+    batches = [torch.from_numpy(ks.ck.encrypt_many(rng.integers(0, M, size=B)).view(np.int64)).cuda() for _ in range(6)]
+    idx = torch.full((B,), int(lut), dtype=torch.int32, device="cuda")
+
+    def run(mode):
+        eng.set_pipeline(mode)
+        outs = [torch.zeros_like(b) for b in batches]
+        for b, o in zip(batches, outs):
+            eng.apply_lookup_table_dev(b.data_ptr(), idx.data_ptr(), o.data_ptr(), B)
+        chain = [torch.zeros_like(batches[0]) for _ in range(5)]
+        src = batches[0]
+        for c in chain:
+            eng.apply_lookup_table_dev(src.data_ptr(), idx.data_ptr(), c.data_ptr(), B)
+            src = c
+        same = torch.zeros_like(batches[0])
+        for b in batches:
+            eng.apply_lookup_table_dev(b.data_ptr(), idx.data_ptr(), same.data_ptr(), B)
+        scratch = batches[1].clone()        # call k reads scratch, call k+1 overwrites it
+        war_out = torch.zeros_like(scratch)
+        eng.apply_lookup_table_dev(scratch.data_ptr(), idx.data_ptr(), war_out.data_ptr(), B)
+        eng.apply_lookup_table_dev(batches[2].data_ptr(), idx.data_ptr(), scratch.data_ptr(), B)
+        eng.synchronize()
+        eng.set_pipeline(0)
+        return [t.cpu().numpy() for t in outs + chain + [same, war_out, scratch]]
+
+    default_serial = run(0)
+    overlapped = run(2)
+    eng.set_variant(16 | 2)                 # every serial call on the two-LWEs-per-CU kernel
+    try:
+        wide_serial = run(0)
+    finally:
+        eng.set_variant(0)
+    assert all(np.array_equal(a, b) for a, b in zip(wide_serial, overlapped))
+    dec = lambda arrs: [ks.ck.decrypt_many(a.view(np.uint64)) for a in arrs]
+    assert all(np.array_equal(a, b) for a, b in zip(dec(default_serial), dec(overlapped)))
+
+
+@pytest.mark.gpu
 def test_pipelined_call_right_after_a_serial_one_and_stream_ordered_inputs(p22):
     """(a) with the throughput mode on, a batch that takes the serial path (more LWEs than CUs) followed at
     once, without synchronisation, by one that takes the pipelined path -- both use the engine's small-ciphertext buffer;
