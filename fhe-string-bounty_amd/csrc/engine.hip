@@ -1107,6 +1107,11 @@ int Engine::kernel_times(double total_ms[2], uint32_t* calls, bool reset) {
     return 0;
 }
 
+#ifdef FHESTR_WALL
+extern "C" int fhe_debug_read_wall(unsigned long long* out, size_t count) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wall), count * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
 #ifdef FHESTR_STAMPS
 extern "C" int fhe_debug_read_stamps(unsigned long long* out, size_t count) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), count * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;

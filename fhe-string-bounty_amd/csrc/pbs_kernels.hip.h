@@ -30,6 +30,11 @@ namespace fhe {
 // segments of one CMUX step of blind_rotate_kernel, summed per wave in scalar registers and stored once
 // after the loop into a buffer nothing else reads (cdna_hip_programming.md section 7, "In-kernel stamps").
 // The fences forbid overlaps the real kernel has: read the SHARES, never this build's run time.
+#ifdef FHESTR_WALL
+// diagnostic build (-DFHESTR_WALL, scripts/wall_spread.py): wall time of every workgroup on the constant 100 MHz clock
+// and the XCD it ran on -- do all workgroups of a launch take the same TIME, not just the same cycles?
+__device__ unsigned long long g_wall[4096 * 2];
+#endif
 #ifdef FHESTR_STAMPS
 constexpr int STAMP_SEGS = 10;
 __device__ unsigned long long g_stamps[4096 * 8 * STAMP_SEGS];
@@ -286,6 +291,9 @@ blind_rotate_kernel(BlindRotateArgs args) {
     // a polynomial group is a whole number of wavefronts here: tell the compiler that g is wave-uniform,
     // so the group-dependent address arithmetic (key rows, LDS planes) runs on the scalar unit
     if constexpr (T % 64 == 0) g = __builtin_amdgcn_readfirstlane(g);
+#ifdef FHESTR_WALL
+    const unsigned long long wall_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const uint32_t sample = blockIdx.x;
     const uint32_t n = args.n;
     const uint64_t* lwe = args.lwe_small + (size_t)sample * (n + 1);
@@ -427,6 +435,14 @@ blind_rotate_kernel(BlindRotateArgs args) {
             cplx x[K1][R];
 #pragma unroll
             for (int m = 0; m < R; m++) x[0][m] = digit_point(st_lo[m], st_hi[m], twist[m], twbias[m]);   // fft/mod.rs:220-239
+#ifdef FHESTR_WALL
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_wall[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime() - wall_t0;
+        g_wall[blockIdx.x * 2 + 1] = xcc & 7u;
+    }
+#endif
 #ifdef FHESTR_STAMPS
             swap10_fwd_stage1(x[0], fc, xre, xim, tau);
             FHE_STAMP(1);    // convert + twist + stage 1 (2 passes, 1 swap transpose, 8 LDS writes)

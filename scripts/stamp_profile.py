@@ -52,5 +52,8 @@ if CLUSTER:
     print(f"{st.shape[0]} workgroups stamped")     # cycles per step (s_memtime: shader clock... 100 MHz ticks?)
 tot = st.sum(axis=2).mean()
 print(f"sum of segments: {tot:.0f} ticks per step and wave")
+per_wg = st.sum(axis=2).mean(axis=1)          # ticks per step, per workgroup
+q = np.percentile(per_wg, [0, 5, 50, 95, 100])
+print(f"per workgroup (ticks per step): min {q[0]:.0f}, 5 % {q[1]:.0f}, median {q[2]:.0f}, 95 % {q[3]:.0f}, max {q[4]:.0f}  (max / median {q[4] / q[2]:.3f})")
 for i, name in enumerate(SEGS):
     print(f"  {i}: {st[:, :, i].mean():8.1f}  {100 * st[:, :, i].mean() / tot:5.1f} %   (waves 0-3 {st[:, :4, i].mean():7.1f}, waves 4-7 {st[:, 4:, i].mean():7.1f})  {name}")
