@@ -12,16 +12,19 @@
 //     thread groups per row split the L(k+1) digit polynomials and swap one partial sum through LDS),
 //     inverse row transforms, stores in place,
 //   * phase 3: inverse column transforms of its columns, torus rounding, accumulate, publish.
-// Per LWE-step the cluster moves 1.5 MB out and 1.5 MB back (+ the 2 MB GGSW all clusters share) through
-// the XCD's L2 instead of 5 MB through HBM by one CU, and an LWE's step is worked on by C CUs at once.
+// Per LWE-step the cluster moves 2 MB out and 2 MB back (T 1 MB, its in-place inverse half 0.5 MB, the published
+// accumulator 0.5 MB; + the 2 MB GGSW all clusters of an XCD share) through the XCD's L2 instead of 5 MB through HBM by
+// one CU, and an LWE's step is worked on by C CUs at once.  With one or two clusters per XCD the exchange stays in L2;
+// at four (6 MB per XCD) it spills to the Infinity Cache and the fabric binds.
 //
 // Hand-over between the workgroups of a cluster: they are on the same XCD BY CONSTRUCTION -- every workgroup
 // reads its XCC id (s_getreg_b32 HW_REG_XCC_ID) and takes a ticket from that XCD's counter, clusters are
 // formed from consecutive tickets of one XCD once the whole grid has arrived -- so the XCD's L2 is their
-// point of coherence: plain stores (write through the CU's L1 into L2), every storing wave's
-// s_waitcnt vmcnt(0), a workgroup barrier, then the workgroup's epoch flag (plain store); consumers poll the
-// C flags and read the exchanged bytes with sc1 loads, which bypass the vector L1 and are served by L2
-// (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility").  Nothing depends on
+// point of coherence: plain stores (write through the CU's L1 into L2), every storing wave's own
+// s_waitcnt vmcnt, an arrival count in LDS whose last wave publishes the workgroup's epoch flag (plain store); every
+// wave polls the cluster's flag line and reads the exchanged bytes with sc1 loads, which bypass the vector L1 and are
+// served by L2 (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"): no workgroup
+// barrier, no fence and no agent-scope atomic inside the CMUX loop (cluster_sync below).  Nothing depends on
 // WHICH workgroups share an XCD: leftover workgroups exit, LWEs are dealt over the clusters that did form,
 // every spin is bounded and raises ctl->error instead of hanging.
 #pragma once
