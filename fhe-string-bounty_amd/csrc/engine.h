@@ -104,6 +104,8 @@ struct Engine {
     uint32_t cluster_last = 0;      // clusters the last checked launch formed
     int cluster_mode = -1;          // -1 automatic (by batch size), 0 never, 1 always (FHESTR_CLUSTER)
     uint32_t cluster_max_batch = 0xFFFFFFFFu;
+    uint32_t cluster_spin_limit = 1u << 22;   // polls before a hand-over wait gives up (FHESTR_CLUSTER_SPIN_LIMIT)
+    uint32_t cluster_test_fault = 0;          // tests only (FHESTR_CLUSTER_TEST_FAULT): epoch one workgroup stays silent at
     int cluster_check();            // after a synchronisation: did a cluster launch give up on a hand-over?
     size_t cap_in = 0, cap_small = 0, cap_small2 = 0, cap_out = 0, cap_idx = 0, cap_pool = 0, cap_meta = 0;
 

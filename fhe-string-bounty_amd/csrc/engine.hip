@@ -273,6 +273,8 @@ int Engine::create(const fhe_params_t& p, int device, Engine** out) {
     e->variant_large = v;
     if (const char* m = getenv("FHESTR_OVERLAP_STREAMS")) e->ovl_streams = std::min((int)Engine::OVL_MAX, std::max(2, atoi(m)));
     if (const char* m = getenv("FHESTR_KS_MFMA")) e->ks_mfma_enabled = atoi(m) != 0;
+    if (const char* m = getenv("FHESTR_CLUSTER_SPIN_LIMIT")) e->cluster_spin_limit = (uint32_t)std::max(64, atoi(m));
+    if (const char* m = getenv("FHESTR_CLUSTER_TEST_FAULT")) e->cluster_test_fault = (uint32_t)std::max(0, atoi(m));   // tests only
     if (const char* m = getenv("FHESTR_CLUSTER")) e->cluster_mode = std::min(1, std::max(-1, atoi(m)));
     if (const char* m = getenv("FHESTR_MULTIBIT_COMBINE_MAX")) e->multibit_combine_max = (uint32_t)std::min(1024, std::max(0, atoi(m)));
     if (env_logr == 0) {   // automatic: "wide" twin (same points per thread => same key layout) for big batches
@@ -810,7 +812,8 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
         // tickets and flags start from zero; the status words behind them are sticky (read by cluster_status())
         HIP_TRY(hipMemsetAsync(d_cluster_ctl, 0, sizeof(ClusterCtl), stream));
         ClusterCtl* ctl = reinterpret_cast<ClusterCtl*>(d_cluster_ctl);
-        BlindRotateClusterArgs ka{a, reinterpret_cast<unsigned char*>(d_cluster_ws), ctl, reinterpret_cast<ClusterStatus*>(ctl + 1)};
+        BlindRotateClusterArgs ka{a, reinterpret_cast<unsigned char*>(d_cluster_ws), ctl, reinterpret_cast<ClusterStatus*>(ctl + 1),
+                                  cluster_spin_limit, cluster_test_fault};
         void* kargs[] = {(void*)&ka};
         HIP_TRY(hipLaunchKernel(v->cluster_fn, dim3(grid), dim3(v->threads), kargs, v->cluster_lds + (size_t)p.n * 4, stream));
         cluster_unchecked = true;

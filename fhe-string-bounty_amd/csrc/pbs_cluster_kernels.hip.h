@@ -99,6 +99,8 @@ struct BlindRotateClusterArgs {
     unsigned char* workspace;    // clusters * WS_BYTES
     ClusterCtl* ctl;
     ClusterStatus* status;
+    uint32_t spin_limit;         // polls before a wait gives up (CLUSTER_SPIN_LIMIT; tests lower it)
+    uint32_t test_fault;         // tests only: member 1 of cluster 0 never publishes its flag of this epoch (0 = off)
 };
 
 template <class RSRC>
@@ -130,7 +132,7 @@ __device__ __forceinline__ uint64_t load_sc1_b64(RSRC rsrc, uint32_t voff) {
 // 128-byte line (byte-masked stores into L2; one request per poll).
 template <int C, int PREFETCHED = 0>
 __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, uint32_t& epoch, uint32_t* s_dead_generic,
-                                             ClusterCtl* ctl, ClusterStatus* status) {
+                                             ClusterCtl* ctl, ClusterStatus* status, uint32_t spin_limit, uint32_t mute_epoch) {
     typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32_t;
     lds_vu32_t* s_dead = (lds_vu32_t*)(uintptr_t)lds_address(s_dead_generic);
     const uint32_t arrive_address = lds_address(s_dead_generic + 1);          // the arrival counter sits behind the dead word
@@ -145,7 +147,7 @@ __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, u
         asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(before) : "v"(arrive_address), "v"(one) : "memory");
     }
     before = __builtin_amdgcn_readfirstlane(before);
-    if (before + 1 == WAVES * epoch && lane == 0)
+    if (before + 1 == WAVES * epoch && lane == 0 && epoch != mute_epoch)
         __hip_atomic_store(flags + member, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     uint32_t spins = 0;
     for (;;) {
@@ -153,7 +155,7 @@ __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, u
         if (__all((int32_t)(v - epoch) >= 0)) break;
         ++spins;
         const bool others_gave_up = (spins & 1023u) == 0 && (*s_dead || __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (spins > CLUSTER_SPIN_LIMIT || others_gave_up) {
+        if (spins > spin_limit || others_gave_up) {
             if (lane == 0) {
                 __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&status->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -167,7 +169,7 @@ __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, u
 #else
 template <int C, int PREFETCHED = 0>
 __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, uint32_t& epoch, uint32_t* s_dead_generic,
-                                             ClusterCtl* ctl, ClusterStatus* status) {
+                                             ClusterCtl* ctl, ClusterStatus* status, uint32_t spin_limit, uint32_t mute_epoch) {
     typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32_t;     // a plain LDS access (a generic pointer would be a
     lds_vu32_t* s_dead = (lds_vu32_t*)(uintptr_t)lds_address(s_dead_generic);   // flat load: it waits for vmcnt(0) as well)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PREFETCHED) : "memory");      // this wave's stores have reached L2
@@ -175,14 +177,14 @@ __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, u
     ++epoch;
     if (threadIdx.x < 64 && !*s_dead) {
         const uint32_t lane = threadIdx.x;
-        if (lane == 0) __hip_atomic_store(flags + member, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0 && epoch != mute_epoch) __hip_atomic_store(flags + member, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         uint32_t spins = 0;
         for (;;) {
             const uint32_t v = lane < (uint32_t)C ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
             if (__all((int32_t)(v - epoch) >= 0)) break;
             ++spins;
             const bool others_gave_up = (spins & 1023u) == 0 && __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (spins > CLUSTER_SPIN_LIMIT || others_gave_up) {
+            if (spins > spin_limit || others_gave_up) {
                 if (lane == 0) {
                     __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&status->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -228,7 +230,7 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
         uint32_t spins = 0;
         bool ok = true;
         while (__hip_atomic_load(&ctl->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-            if (++spins > CLUSTER_SPIN_LIMIT) { ok = false; break; }
+            if (++spins > (ca.spin_limit > (1u << 16) ? ca.spin_limit : (1u << 16))) { ok = false; break; }
             __builtin_amdgcn_s_sleep(4);
         }
         uint32_t base = 0, total = 0, mine = 0;
@@ -328,6 +330,7 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
     }
     uint32_t* flags = &ctl->flags[cluster][0][0];
     uint32_t epoch = 0;
+    const uint32_t mute_epoch = (ca.test_fault && cluster == 0 && member == 1) ? ca.test_fault : 0u;
 
     const uint32_t n = args.n;
     const uint32_t bL = args.base_log * L;
@@ -363,7 +366,7 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
                 }
             }
         }
-        cluster_sync<C>(flags, member, epoch, &s_dead, ctl, ca.status);
+        cluster_sync<C>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch);
 
         FHE_STAMP_DECL;
         FHE_STAMP(-1);
@@ -444,7 +447,7 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
             asm volatile("" ::: "memory");         // after the phase's stores in issue order
             issue_key(0);
             asm volatile("" ::: "memory");
-            cluster_sync<C, K1 * R>(flags, member, epoch, &s_dead, ctl, ca.status);
+            cluster_sync<C, K1 * R>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch);
             FHE_STAMP(2);
 
             // ---- phase 2: row transforms, multiply-accumulate with the GGSW, inverse row transforms, in place ----
@@ -512,7 +515,7 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
                 }
             }
             FHE_STAMP(3);
-            cluster_sync<C>(flags, member, epoch, &s_dead, ctl, ca.status);
+            cluster_sync<C>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch);
             FHE_STAMP(4);
 
             // ---- phase 3: inverse column transforms, untwist, torus rounding, accumulate, publish ----
@@ -542,7 +545,7 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
                 }
             }
             FHE_STAMP(5);
-            cluster_sync<C>(flags, member, epoch, &s_dead, ctl, ca.status);
+            cluster_sync<C>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch);
             FHE_STAMP(6);
         }
 #ifdef FHESTR_STAMPS

@@ -11,6 +11,8 @@ import oracle as O
 from conftest import gpu_engine, keyset, torus_distance, to_fhestr_params
 
 pytestmark = pytest.mark.gpu
+import os as _os
+ROOT_DIR = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
 
 SHAPES = [O.TOY_N32768] + [p for p in O.TOY_SHAPES if p.N >= 16384]
 
@@ -90,3 +92,40 @@ def test_cluster_kernel_more_lwes_than_clusters(params):
         assert np.array_equal(ks.ck.decrypt_many(a), ks.ck.decrypt_many(b))
     finally:
         eng.set_cluster_mode(-1)
+
+
+def test_a_missing_hand_over_is_reported_not_hung():
+    """Fault injection (FHESTR_CLUSTER_TEST_FAULT): one workgroup of one cluster never publishes one of its epoch flags.
+    The waits of that cluster give up after the (lowered) poll limit, the launch drains, the next host-visible
+    completion point returns an error -- and the engine is usable again afterwards.  A hand-over that never comes
+    must never hang the GPU."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "fhe-string-bounty_amd"); sys.path.insert(0, ".")
+import fhestr, oracle as O
+sys.path.insert(0, "tests")
+from conftest import to_fhestr_params
+p = O.TOY_N32768
+ck = O.ClientKey(p, 0x5EED0001); sk = O.ServerKey(ck)
+eng = fhestr.Engine(to_fhestr_params(p), 0); eng.load_keys(sk.bsk, sk.ksk)
+M = p.msg_mod * p.carry_mod
+lut, _ = eng.generate_lookup_table(lambda x: (x + 1) % M)
+cts = ck.encrypt_many([1, 2, 3], O.Rng(1, 1))
+eng.set_cluster_mode(1)
+try:
+    eng.apply_lookup_table(cts, np.full(3, lut, dtype=np.uint32))
+    print("NO ERROR")
+except fhestr.FheError as e:
+    print("ERROR:", e)
+'''
+    env = dict(os.environ, FHESTR_CLUSTER_TEST_FAULT="5", FHESTR_CLUSTER_SPIN_LIMIT="4096")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT_DIR, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ERROR:" in r.stdout and "hand-over timed out" in r.stdout, r.stdout + r.stderr[-1000:]
+    # the same engine configuration without the fault still works (fresh process: the fault hook is an env switch)
+    env.pop("FHESTR_CLUSTER_TEST_FAULT")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT_DIR, capture_output=True, text=True, timeout=300)
+    assert "NO ERROR" in r.stdout, r.stdout + r.stderr[-1000:]
