@@ -12,7 +12,7 @@
 
 // bumped whenever a device kernel changes; profiles/r03_counters.json records the revision its
 // rocprofv3 counters were taken on and bench.py only attaches them to a matching build
-#define FHESTR_KERNEL_REVISION "r03.1"
+#define FHESTR_KERNEL_REVISION "r03.2"
 
 namespace fhe {
 
@@ -60,7 +60,8 @@ struct Engine {
     size_t pipe_out_bytes[2] = {0, 0};
     // mode 2 (overlapped batches): calls rotate over ovl_streams streams (slot 0 = the engine stream, 1 = ks_stream)
     static constexpr int OVL_MAX = 4;
-    int ovl_streams = 3;
+    int ovl_streams = 2;
+    uint32_t wide_fair_shift = 13;           // two-LWEs-per-CU kernel: log2 ticks (100 MHz) of the priority time slice, 0 = off (FHESTR_WIDE_FAIR)
     hipStream_t ovl_stream[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ovl_done[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};
     const void* ovl_in[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};

@@ -271,6 +271,7 @@ int Engine::create(const fhe_params_t& p, int device, Engine** out) {
     e->device = device;
     e->variant = v;
     e->variant_large = v;
+    if (const char* m = getenv("FHESTR_WIDE_FAIR")) e->wide_fair_shift = (uint32_t)std::min(20, std::max(0, atoi(m)));
     if (const char* m = getenv("FHESTR_OVERLAP_STREAMS")) e->ovl_streams = std::min((int)Engine::OVL_MAX, std::max(2, atoi(m)));
     if (const char* m = getenv("FHESTR_KS_MFMA")) e->ks_mfma_enabled = atoi(m) != 0;
     if (const char* m = getenv("FHESTR_CLUSTER_SPIN_LIMIT")) e->cluster_spin_limit = (uint32_t)std::max(64, atoi(m));
@@ -725,9 +726,13 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
     if (!d_fbsk) return fail("keys not loaded");
     if (n_luts == 0) return fail("no lookup table uploaded");
     BlindRotateArgs a{d_sm, d_lut_idx, d_luts, d_fbsk, d_big, p.n, p.pbs_base_log, count};
+    a.grouping = 0;
+    // two-LWEs-per-CU kernel: fair time-sliced priorities when every CU gets an even number of workgroups (pbs_kernels.hip.h)
+    a.fair_shift = (!two_per_cu && wide_fair_shift && count > (uint32_t)cu_count && (((count + (uint32_t)cu_count - 1) / (uint32_t)cu_count) & 1u) == 0) ? wide_fair_shift : 0u;
     void* args[] = {(void*)&a};
     if (two_per_cu) {          // overlapped throughput mode: the compact layout whatever the batch size, on the given stream
         const BrVariant* w = variant_large;
+        a.fair_shift = wide_fair_shift;      // the two launches that share the GPU progress at the same rate (110 k -> 122 k PBS/s)
         HIP_TRY(hipLaunchKernel(w->rotate_fn, dim3(count), dim3(w->threads), args, w->lds_bytes + (size_t)p.n * w->lds_per_n, on ? on : stream));
         return 0;
     }
@@ -863,10 +868,11 @@ int Engine::ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint
     ring_used++;
     if (allow_pipeline && pipeline == 2 && stream == own_stream && variant_large != variant && variant_large->wide &&
         !variant->extprod_fn && !variant->combine_fn && count <= (uint32_t)cu_count) {
-        // Overlapped batches (fhe_engine_set_pipeline(2)): consecutive calls rotate over OVL_STREAMS streams and run on the
-        // two-LWEs-per-CU kernel.  Two launches fill the GPU, the third queues behind them and its workgroups take the
-        // slots the oldest launch frees one by one -- the GPU stays full like inside one 4,096-LWE launch (121 k PBS/s)
-        // although every batch has 256 LWEs; the price is each call's latency.  Same ordering rules as mode 1, plus
+        // Overlapped batches (fhe_engine_set_pipeline(2)): consecutive calls alternate between ovl_streams (2) streams and
+        // run on the two-LWEs-per-CU kernel with time-sliced priorities (BlindRotateArgs::fair_shift), so two 256-LWE
+        // launches share every CU and progress at the same rate -- the pace of a 512-LWE launch (2.09 ms per call,
+        // 122 k PBS/s) although every batch has 256 LWEs; the price is each call's latency (4.1 ms).  Three streams
+        // measured slower (119 k): the third launch's keyswitch waits for idle CUs.  Same ordering rules as mode 1, plus
         // write-after-write / write-after-read against the calls still in flight on the other streams.  Results are
         // those of the large-batch kernel.
         const int ns = ovl_streams;

@@ -53,6 +53,15 @@ __device__ unsigned long long g_stamps[4096 * 8 * STAMP_SEGS];
 #define FHE_STAMP(idx) do {} while (0)
 #endif
 
+// Two workgroups of the two-LWEs-per-CU kernel share every SIMD, and the hardware arbitrates vector issue by age: the
+// workgroup that arrived first runs at almost its solo speed (3.2 ms), the other one gets the leftovers and then finishes
+// alone (5.0 ms; profiles/r03_wide_wall.txt: a 512-LWE launch takes as long as its slowest workgroup).  With
+// BlindRotateArgs::fair_shift = n > 0 the two take turns at s_setprio 1 in time slices of 2^n ticks of the 100 MHz clock,
+// complementary by the parity of a ticket per hardware CU (monotonic across launches), so both progress at the same rate
+// and finish together: 512 LWEs 4.64 -> 4.20 ms, 1024 LWEs 8.79 -> 8.24 ms.  The host turns it on when every CU gets an
+// even number of workgroups; with an odd number the age order is the better pipeline (768 LWEs: 6.9 ms unfair, 7.3 fair).
+__device__ uint32_t g_cu_tickets[2048];
+
 struct BlindRotateArgs {
     const uint64_t* lwe_small;   // [B][n+1]
     const uint32_t* lut_idx;     // [B] or nullptr
@@ -63,6 +72,7 @@ struct BlindRotateArgs {
     uint32_t base_log;           // PBS decomposition base log
     uint32_t batch;
     uint32_t grouping;           // EXTPROD kernels only: mask elements per step (multi-bit grouping factor)
+    uint32_t fair_shift;         // two-LWEs-per-CU kernel only: log2 ticks of the priority time slice (0 = hardware age order)
 };
 
 // ((x >> (63 - bL)) + 1) >> 1 masked to bL bits == closest_representable(x) >> (64 - bL)
@@ -629,6 +639,9 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
     uint32_t* lds_d = reinterpret_cast<uint32_t*>(lds_tw + CFG::LDS_TW / 16);               // [n]
 
     const int tau = threadIdx.x;
+#ifdef FHESTR_WALL
+    const unsigned long long wall_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const uint32_t sample = blockIdx.x;
     const uint32_t n = args.n;
     const uint64_t* lwe = args.lwe_small + (size_t)sample * (n + 1);
@@ -637,6 +650,15 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
     if (PL::SWAP && (acc_address & (8u * N - 1u))) __builtin_trap();
     const uint32_t bL = args.base_log * L;
     const uint32_t dbias = decomp_bias_constant(bL <= 31 ? bL : 31);
+    if (args.fair_shift && threadIdx.x == 0) {
+        uint32_t fair_parity;
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        fair_parity = atomicAdd(&g_cu_tickets[((xcc & 7u) << 8) | ((hw >> 8) & 0xFFu)], 1u) & 1u;
+        reinterpret_cast<uint32_t*>(lds_x)[0] = fair_parity;     // a plane word, read back before the first transform (no static LDS: the
+                                                                 // accumulator copy must stay 8N-aligned at the start of the dynamic segment)
+    }
 
     for (uint32_t i = threadIdx.x; i < n; i += CFG::THREADS) {
         const uint64_t a = lwe[i];
@@ -688,11 +710,21 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
     const uint32_t key_off = (uint32_t)tau * 16u;
     const auto key_rsrc = key_resource(args.fbsk, (size_t)n * GGSW_ELEMS * 16);
 
+    const uint32_t fair_shift = args.fair_shift;
+    uint32_t fair_turn = 0;
+    if (fair_shift) {
+        fair_turn = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<uint32_t*>(lds_x)[0]);
+        __syncthreads();
+    }
     uint32_t d_next = lds_d[0];
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)d_next);   // workgroup-uniform: scalar
         d_next = lds_d[i + 1 < n ? i + 1 : i];
         if (d == 0xFFFFFFFFu) continue;
+        if (fair_shift) {
+            if ((((uint32_t)(__builtin_amdgcn_s_memrealtime() >> fair_shift)) ^ fair_turn) & 1u) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         const Rotation<PL, LOGN> rot(d, tau);
         const double2* bk0 = fbsk + (size_t)i * GGSW_ELEMS;
 
@@ -793,6 +825,12 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
         __syncthreads();
     }
 
+#ifdef FHESTR_WALL
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        g_wall[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime() - wall_t0;
+        g_wall[blockIdx.x * 2 + 1] = wall_t0;
+    }
+#endif
     uint64_t* out = args.lwe_out + (size_t)sample * ((size_t)(K1 - 1) * N + 1);
 #pragma unroll
     for (int p = 0; p < K1; p++)
