@@ -97,7 +97,7 @@ int fhe_engine_set_variant(fhe_engine *eng, int log2_points);
  * after fhe_engine_synchronize.
  * on = 2, "overlapped batches": consecutive calls alternate between two streams and run on the two-LWEs-per-CU kernel, so
  * two batches share the GPU like the two halves of a 512-LWE launch: 256-LWE batches reach the large-batch rate (about
- * 120 k instead of 100 k PBS/s) for the price of each call's latency (4.2 instead of 2.6 ms).  Same ordering contract,
+ * 122 k instead of 100 k PBS/s) for the price of each call's latency (4.1 instead of 2.6 ms).  Same ordering contract,
  * plus: a call is also ordered after the previous one if it WRITES what that call reads or writes.  Results are the
  * large-batch kernel's: decrypt-identical to the serial ones and within the same noise, not bit-identical to mode 0 / 1
  * (two f64 transform schedules round differently); bit-identical to serial calls of more than one LWE per CU. */
