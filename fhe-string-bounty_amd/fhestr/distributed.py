@@ -54,7 +54,13 @@ class GpuBackend:
         plan.engine.set_stream(torch.cuda.current_stream(device).cuda_stream)
 
     def alloc_pool(self, slots):
-        return self.torch.zeros((slots, self.big), dtype=self.torch.int64, device=self.device)
+        # one pool per backend, reused across runs (a fresh 100+ MB allocation per operation costs milliseconds when the
+        # caching allocator has to go back to the driver); zeroed each time like a fresh one
+        pool = getattr(self, "_pool", None)
+        if pool is None or pool.shape[0] != slots:
+            pool = self._pool = self.torch.empty((slots, self.big), dtype=self.torch.int64, device=self.device)
+        pool.zero_()
+        return pool
 
     def load_inputs(self, pool, inputs, n_inputs):
         if isinstance(inputs, self.torch.Tensor):      # already resident in HBM (int64 view of the u64 words)
