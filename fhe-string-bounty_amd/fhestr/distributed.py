@@ -42,13 +42,14 @@ class GpuBackend:
     """Product backend: pool in HBM (torch tensor), HIP kernels via the C ABI, RCCL all-gather.
     staged=True gathers through host memory instead (gloo group: rehearsing several ranks on one GPU)."""
 
-    def __init__(self, plan, device, group=None, staged=False):
+    def __init__(self, plan, device, group=None, staged=False, reuse_pool=True):
         import torch
         self.torch = torch
         self.plan = plan
         self.device = device
         self.group = group
         self.staged = staged
+        self.reuse_pool = reuse_pool     # False: every alloc_pool call returns its own tensor (several simulated ranks)
         self.big = plan.params.big_size
         # kernels and collectives on the same stream: no host synchronisation between them
         plan.engine.set_stream(torch.cuda.current_stream(device).cuda_stream)
@@ -56,6 +57,8 @@ class GpuBackend:
     def alloc_pool(self, slots):
         # one pool per backend, reused across runs (a fresh 100+ MB allocation per operation costs milliseconds when the
         # caching allocator has to go back to the driver); zeroed each time like a fresh one
+        if not self.reuse_pool:
+            return self.torch.zeros((slots, self.big), dtype=self.torch.int64, device=self.device)
         pool = getattr(self, "_pool", None)
         if pool is None or pool.shape[0] != slots:
             pool = self._pool = self.torch.empty((slots, self.big), dtype=self.torch.int64, device=self.device)

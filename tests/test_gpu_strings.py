@@ -218,7 +218,7 @@ class _LoopbackRanks:
         import torch
         from fhestr.distributed import GpuBackend
         self.torch, self.plan, self.world = torch, plan, world
-        self.backend = GpuBackend(plan, torch.device("cuda", 0))
+        self.backend = GpuBackend(plan, torch.device("cuda", 0), reuse_pool=False)
         self.info = plan.info()
         self.levels = [plan.level_info(l) for l in range(self.info["n_levels"])]
 
