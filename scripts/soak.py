@@ -3,7 +3,7 @@
     python3 scripts/soak.py [batches] [batch]     (default 100 x 1024 = 102,400 PBS; GPU box)
 
 PARAM_MESSAGE_2_CARRY_2_KS_PBS, 16 random tables, fresh ciphertexts; alternates serial calls, pipelined calls
-(fhe_engine_set_pipeline) on 256-LWE chunks and large batches (wide kernel).  The parameter set's failure
+(fhe_engine_set_pipeline modes 1 and 2) on 256-LWE chunks and large batches (wide kernel).  The parameter set's failure
 probability is 2^-40: any mismatch here is a bug, not noise."""
 import sys
 import numpy as np
@@ -28,16 +28,16 @@ for it in range(NB):
     d_in = torch.from_numpy(cts.view(np.int64)).cuda()
     d_idx = torch.from_numpy(luts[sel].view(np.int32)).cuda()
     d_out = torch.zeros_like(d_in)
-    mode = it % 3
+    mode = it % 4
     if mode == 0:                       # one large batch (wide kernel above 256 LWEs)
         eng.apply_lookup_table_dev(d_in.data_ptr(), d_idx.data_ptr(), d_out.data_ptr(), B)
-    else:                               # 256-LWE chunks, serial or pipelined
-        eng.set_pipeline(mode == 2)
+    else:                               # 256-LWE chunks: serial, keyswitch-shadow pipeline, overlapped on two streams
+        eng.set_pipeline(mode - 1)
         for lo in range(0, B, 256):
             n = min(256, B - lo)
             eng.apply_lookup_table_dev(d_in[lo:].data_ptr(), d_idx[lo:].data_ptr(), d_out[lo:].data_ptr(), n)
         eng.synchronize()
-        eng.set_pipeline(False)
+        eng.set_pipeline(0)
     eng.synchronize()
     got = ck.decrypt(d_out.cpu().numpy().view(np.uint64))
     bad += int((got != tables[sel, msgs]).sum())
