@@ -623,7 +623,7 @@ int Engine::lut_upload(const uint64_t* acc, uint32_t* id) {
         uint64_t* nl = nullptr;
         HIP_TRY(hipMalloc((void**)&nl, new_cap));
         if (d_luts) {
-            HIP_TRY(hipStreamSynchronize(stream));
+            if (sync_all_streams()) return 1;      // pipelined calls on the other streams may still read the old table array
             HIP_TRY(hipMemcpy(nl, d_luts, (size_t)n_luts * glwe * 8, hipMemcpyDeviceToDevice));
             HIP_TRY(hipFree(d_luts));
         }
