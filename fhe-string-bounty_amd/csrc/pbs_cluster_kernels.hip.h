@@ -373,6 +373,12 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t d = lds_d[i];
             if (d == 0xFFFFFFFFu) continue;       // a_i == 0 (bootstrap.rs:281): the same for the whole cluster
+#ifdef FHESTR_WALL
+            // diagnostic build (scripts/wall_spread_cluster.py): when does each cluster reach steps 0, n/8, 2n/8, ...
+            // of its first LWE -- do the clusters of one XCD stay in step (and so share the GGSW rows in L2)?
+            if (tid == 0 && member == 0 && sample == cluster && i % (n / 8) == 0 && i / (n / 8) < 8)
+                g_wall[cluster * 8 + i / (n / 8)] = __builtin_amdgcn_s_memrealtime();
+#endif
 
             // ---- phase 1: rotate, subtract, decompose, twist, column transforms, twiddle -> T ----
             {
@@ -432,7 +438,13 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
             FHE_STAMP(1);
             // the GGSW rows of this half's first digit polynomial do not depend on the hand-over: request them now
             const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(args.fbsk)) + (size_t)i * GGSW_BYTES, 0, (int)GGSW_BYTES, 0x00020000);
+                const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(args.fbsk)) +
+#ifdef FHESTR_CL_KEY0      // diagnostic build: every step reads the first GGSW (wrong results; what does the key stream cost?)
+                    (size_t)0 * GGSW_BYTES,
+#else
+                    (size_t)i * GGSW_BYTES,
+#endif
+                    0, (int)GGSW_BYTES, 0x00020000);
             double2 bv[K1][R];
             auto issue_key = [&](int uu) {
 #pragma unroll
