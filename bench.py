@@ -37,7 +37,8 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=40,
+                    help="untimed steps (default 40 = 84 ms: after an idle period the part needs tens of ms to ramp its clock, profiles/r03_after_idle.txt)")
     ap.add_argument("--batch", type=int, default=256, help="LWEs per step per GPU")
     ap.add_argument("--log2-points", type=int, default=0, help="blind-rotate variant (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -401,11 +402,24 @@ def bench_p44(fhestr, local_rank):
                                    "traffic_source": "profiles/r03_p44_counters.json (static rocprofv3 --pmc passes, " + cj.get("p44_command", "") + ")"}
         except Exception:
             pass
-        # config 5: 1024-char string, to_lower and replace (4-char clear pattern), one call each
-        ops = fhestr.FheStringOps(eng)
+        # config 5: 1024-char string, to_lower and replace (4-char clear pattern), one call each.  268 MB go each way:
+        # host buffers from fhe_host_alloc (page-locked), allocated before the clock starts; to_lower is also timed
+        # with pageable numpy arrays, the way every other host figure of this file is taken
         words = [b"The ", b"quick ", b"BROWN ", b"fox ", b"Jumps ", b"over ", b"the ", b"LAZY ", b"dog. "]
         s = b"".join(words[int(i)] for i in rng.integers(0, len(words), size=400))[:1000]
-        es = ck.encrypt(fhestr.string_to_blocks(P, s, 1024))
+        es_pageable = ck.encrypt(fhestr.string_to_blocks(P, s, 1024))
+        es = fhestr.pinned_empty(es_pageable.shape)
+        es[...] = es_pageable
+        locked = {}
+
+        def locked_out(shape):
+            key = tuple(int(d) for d in shape)
+            if key not in locked:
+                locked[key] = fhestr.pinned_empty(key)
+            return locked[key]
+
+        locked_out(es.shape)
+        ops = fhestr.FheStringOps(eng, out_alloc=locked_out)
         dec = lambda ct: fhestr.blocks_to_string(P, ck.decrypt(ct))
         strings = {}
         for name, fn, want, plan_args in (
@@ -416,8 +430,12 @@ def bench_p44(fhestr, local_rank):
             res = fn()
             ms = (time.perf_counter() - t0) * 1e3
             info = fhestr.Plan.string_op(eng, *plan_args).info()
-            strings[name] = {"ms_per_op_inputs_from_host": ms, "n_pbs": info["n_pbs"], "levels": info["n_levels"],
-                             "correct": bool(dec(res) == want), "pbs_per_s": info["n_pbs"] / (ms * 1e-3)}
+            strings[name] = {"ms_per_op_inputs_from_host": ms, "host_buffers": "page-locked (fhe_host_alloc)", "n_pbs": info["n_pbs"],
+                             "levels": info["n_levels"], "correct": bool(dec(res) == want), "pbs_per_s": info["n_pbs"] / (ms * 1e-3)}
+        t0 = time.perf_counter()
+        res = fhestr.FheStringOps(eng).to_lower(es_pageable)
+        strings["to_lower_1024"]["ms_per_op_pageable_host_buffers"] = (time.perf_counter() - t0) * 1e3
+        strings["to_lower_1024"]["correct"] = bool(strings["to_lower_1024"]["correct"] and dec(res) == s.lower())
         out["string_ops"] = strings
         return out
     finally:

@@ -542,6 +542,23 @@ int fhe_noise_model(const fhe_params_t* params, double out[6]) {
     API_END
 }
 
+int fhe_host_alloc(size_t bytes, void** out) {
+    API_BEGIN
+    CHECK_PTR(out);
+    *out = nullptr;
+    if (bytes == 0) return 0;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) { *out = nullptr; return fhe::fail("fhe_host_alloc: hipHostMalloc failed"); }
+    return 0;
+    API_END
+}
+
+int fhe_host_free(void* ptr) {
+    API_BEGIN
+    if (ptr && hipHostFree(ptr) != hipSuccess) return fhe::fail("fhe_host_free: not a buffer of fhe_host_alloc");
+    return 0;
+    API_END
+}
+
 int fhe_noise_model_is_calibrated(const fhe_params_t* params) {
     return params && fhe::noise_model_is_calibrated(*params) ? 1 : 0;
 }

@@ -147,6 +147,7 @@ EXPORTS = [
     "fhe_plan_output", "fhe_plan_finalize", "fhe_plan_info", "fhe_plan_level_info", "fhe_plan_export_level",
     "fhe_plan_run", "fhe_plan_run_level_rank_dev", "fhe_plan_gather_outputs_dev", "fhe_str_plan_create",
     "fhe_plan_level_rank_info", "fhe_plan_noise_info", "fhe_noise_model", "fhe_noise_model_is_calibrated", "fhe_plan_set_noise_budget",
+    "fhe_host_alloc", "fhe_host_free",
     "fhe_plan_pbs_signed", "fhe_plan_set_owner_hint",
     "fhe_str_to_upper", "fhe_str_to_lower", "fhe_plan_create_offline", "fhe_str_plan_create_offline",
     "fhe_str_trim_start", "fhe_str_trim_end", "fhe_str_strip", "fhe_str_replace", "fhe_str_replace_clear",
@@ -245,6 +246,8 @@ def lib() -> C.CDLL:
     sig("fhe_plan_noise_info", vp, C.POINTER(C.c_double))
     sig("fhe_noise_model", PP, C.POINTER(C.c_double))
     sig("fhe_noise_model_is_calibrated", PP)
+    sig("fhe_host_alloc", C.c_size_t, C.POINTER(vp))
+    sig("fhe_host_free", vp)
     sig("fhe_plan_set_noise_budget", vp, C.c_double)
     sig("fhe_plan_pbs_signed", vp, u32, u32, C.POINTER(u32))
     sig("fhe_plan_set_owner_hint", vp, i32)
@@ -299,6 +302,21 @@ def chacha20_block(key: bytes, counter: int, stream: int) -> np.ndarray:
     kb = (C.c_uint8 * 32)(*seed_bytes(key))
     _check(lib().fhe_chacha20_block(kb, C.c_uint64(counter), C.c_uint64(stream), _ptr(out)))
     return out
+
+
+def pinned_empty(shape, dtype=np.uint64):
+    """numpy array in page-locked host memory (fhe_host_alloc): host <-> GPU copies of it run at the full PCIe rate and
+    never page-fault.  Freed when the array (and every view of it) is gone."""
+    import weakref
+    shape = tuple(int(d) for d in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if shape else 1
+    ptr = C.c_void_p()
+    _check(lib().fhe_host_alloc(max(1, n * dt.itemsize), C.byref(ptr)))
+    buf = (C.c_uint8 * max(1, n * dt.itemsize)).from_address(ptr.value)
+    arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+    weakref.finalize(buf, lib().fhe_host_free, C.c_void_p(ptr.value))
+    return arr
 
 
 def noise_model_is_calibrated(params: "Params") -> bool:
@@ -800,9 +818,12 @@ class FheStringOps:
     """FheString operator surface over one engine (eq/ne/starts_with/ends_with/contains/find/
     to_upper/to_lower).  Strings are (cap*blocks, kN+1) arrays of big-key LWEs (see string_to_blocks)."""
 
-    def __init__(self, engine: Engine):
+    def __init__(self, engine: Engine, out_alloc=None):
+        """out_alloc(shape) -> uint64 array the results are written into (default: np.zeros; pass fhestr.pinned_empty --
+        or a cache of such buffers -- for large strings: pageable memory moves at a fraction of the PCIe rate)."""
         self.engine = engine
         self.bpc = blocks_per_char(engine.params)
+        self._alloc = out_alloc or (lambda shape: np.zeros(shape, dtype=np.uint64))
 
     def _cap(self, ct):
         ct = _u64(ct).reshape(-1, self.engine.params.big_size)
@@ -814,7 +835,7 @@ class FheStringOps:
         while (self.engine.params.msg_mod ** n_dig) < a_cap + 1:
             n_dig += 1
         n_out = 1 + n_dig if op in ("find", "rfind") else 1
-        out = np.zeros((n_out, self.engine.params.big_size), dtype=np.uint64)
+        out = self._alloc((n_out, self.engine.params.big_size))
         if isinstance(b, (bytes, bytearray)):
             buf = (C.c_uint8 * max(1, len(b)))(*b)
             _check(getattr(lib(), f"fhe_str_{op}_clear")(self.engine.handle, _ptr(a), a_cap, buf, len(b), _ptr(out)))
@@ -844,20 +865,20 @@ class FheStringOps:
 
     def len(self, a):
         a, a_cap = self._cap(a)
-        out = np.zeros((self._n_digits(a_cap), self.engine.params.big_size), dtype=np.uint64)
+        out = self._alloc((self._n_digits(a_cap), self.engine.params.big_size))
         _check(lib().fhe_str_len(self.engine.handle, _ptr(a), a_cap, _ptr(out)))
         return out
 
     def is_empty(self, a):
         a, a_cap = self._cap(a)
-        out = np.zeros((1, self.engine.params.big_size), dtype=np.uint64)
+        out = self._alloc((1, self.engine.params.big_size))
         _check(lib().fhe_str_is_empty(self.engine.handle, _ptr(a), a_cap, _ptr(out)))
         return out[0]
 
     def _strip_affix(self, op, a, pat):
         """pat: clear bytes, or an encrypted (zero padded) pattern."""
         a, a_cap = self._cap(a)
-        out = np.zeros((1 + a.shape[0], self.engine.params.big_size), dtype=np.uint64)
+        out = self._alloc((1 + a.shape[0], self.engine.params.big_size))
         if isinstance(pat, (bytes, bytearray)):
             buf = (C.c_uint8 * max(1, len(pat)))(*pat)
             _check(getattr(lib(), f"fhe_str_{op}_clear")(self.engine.handle, _ptr(a), a_cap, buf, len(pat), _ptr(out)))
@@ -871,7 +892,7 @@ class FheStringOps:
 
     def _unary(self, op, a):
         a, a_cap = self._cap(a)
-        out = np.zeros_like(a)
+        out = self._alloc(a.shape)
         _check(getattr(lib(), f"fhe_str_{op}")(self.engine.handle, _ptr(a), a_cap, _ptr(out)))
         return out
 
@@ -888,7 +909,7 @@ class FheStringOps:
         big = self.engine.params.big_size
         clear = isinstance(frm, (bytes, bytearray))
         if out_cap is None:
-            out = np.zeros_like(a)
+            out = self._alloc(a.shape)
             if clear:
                 if len(frm) != len(to):
                     raise FheError("replace: `from` and `to` of different lengths need an output capacity (out_cap)")
@@ -903,7 +924,7 @@ class FheStringOps:
                 both = np.concatenate([frm, to])
                 _check(lib().fhe_str_replace(self.engine.handle, _ptr(a), a_cap, _ptr(both), f_cap, _ptr(out)))
             return out
-        out = np.zeros((out_cap * self.bpc, big), dtype=np.uint64)
+        out = self._alloc((out_cap * self.bpc, big))
         if clear:
             fb = (C.c_uint8 * max(1, len(frm)))(*frm)
             tb = (C.c_uint8 * max(1, len(to)))(*to)
@@ -920,18 +941,18 @@ class FheStringOps:
         """a ++ b (padding of a removed); b encrypted (any capacity) or clear bytes."""
         a, a_cap = self._cap(a)
         if isinstance(b, (bytes, bytearray)):
-            out = np.zeros(((a_cap + len(b)) * self.bpc, self.engine.params.big_size), dtype=np.uint64)
+            out = self._alloc(((a_cap + len(b)) * self.bpc, self.engine.params.big_size))
             buf = (C.c_uint8 * max(1, len(b)))(*b)
             _check(lib().fhe_str_concat_clear(self.engine.handle, _ptr(a), a_cap, buf, len(b), _ptr(out)))
         else:
             b, b_cap = self._cap(b)
-            out = np.zeros(((a_cap + b_cap) * self.bpc, self.engine.params.big_size), dtype=np.uint64)
+            out = self._alloc(((a_cap + b_cap) * self.bpc, self.engine.params.big_size))
             _check(lib().fhe_str_concat(self.engine.handle, _ptr(a), a_cap, _ptr(b), b_cap, _ptr(out)))
         return out
 
     def repeat(self, a, count: int):
         a, a_cap = self._cap(a)
-        out = np.zeros((count * a_cap * self.bpc, self.engine.params.big_size), dtype=np.uint64)
+        out = self._alloc((count * a_cap * self.bpc, self.engine.params.big_size))
         _check(lib().fhe_str_repeat_clear(self.engine.handle, _ptr(a), a_cap, count, _ptr(out)))
         return out
 

@@ -203,6 +203,13 @@ int fhe_plan_info(const fhe_plan *plan, uint32_t info[6]);
 int fhe_plan_noise_info(const fhe_plan *plan, double info[4]);
 /* out[6] = {V_pbs, V_ks, V_ms (variances, torus = 1), delta/2, default budget, log2 p_fail at it} */
 int fhe_noise_model(const fhe_params_t *params, double out[6]);
+/* Page-locked host memory (hipHostMalloc).  Every *_host entry point and every FheString call takes plain host
+ * pointers; pageable ones move at 3-10 GB/s and page-fault on first touch, buffers from fhe_host_alloc move at the
+ * full PCIe rate -- worth it for 1024-char strings under PARAM_MESSAGE_4_CARRY_4 (268 MB each way).  The
+ * reference has no counterpart (its ciphertexts are Vec<u64> on the heap, entities/lwe_ciphertext.rs:598-625).
+ * fhe_host_free(NULL) is a no-op. */
+int fhe_host_alloc(size_t bytes, void **out);
+int fhe_host_free(void *ptr);
 /* 1 if the model's PBS-output variance has been checked against this engine's measured noise for the shape
  * (N, k, level, grouping factor) of `params`; shapes that have not carry a 4x safety factor in the budget. */
 int fhe_noise_model_is_calibrated(const fhe_params_t *params);

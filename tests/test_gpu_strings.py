@@ -430,3 +430,30 @@ def test_p22_general_replace_64_chars(p22):
         want = s.replace(frm, to)
         got = fhestr.blocks_to_string(P, _dec(p22, ops.replace(es, frm, to, out_cap=64)))
         assert got == want
+
+
+def test_page_locked_host_buffers_give_the_same_results(toy_k1):
+    """fhe_host_alloc / fhestr.pinned_empty: operands and results in page-locked host memory (the fast path for
+    1024-char strings, bench.py p44) -- same ciphertexts as with pageable numpy arrays, buffers freed with the arrays."""
+    import fhestr
+    eng = gpu_engine(toy_k1)
+    s = b"Hello, World"
+    pageable = _enc(toy_k1, s, 16)
+    locked = fhestr.pinned_empty(pageable.shape)
+    locked[...] = pageable
+    calls = []
+
+    def alloc(shape):
+        calls.append(tuple(shape))
+        return fhestr.pinned_empty(shape)
+
+    want = fhestr.FheStringOps(eng).to_lower(pageable)
+    got = fhestr.FheStringOps(eng, out_alloc=alloc).to_lower(locked)
+    assert calls == [pageable.shape]
+    assert np.array_equal(got, want)          # the blind rotation is deterministic: identical words
+    assert fhestr.blocks_to_string(eng.params, _dec(toy_k1, got)) == s.lower()
+    hit = fhestr.FheStringOps(eng, out_alloc=alloc).contains(locked, b"World")
+    assert _dec(toy_k1, hit)[0] == 1
+    del locked, got, hit
+    zero = fhestr.pinned_empty((0, 3))
+    assert zero.shape == (0, 3)
