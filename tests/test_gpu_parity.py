@@ -664,3 +664,30 @@ def test_blind_rotation_against_an_exact_integer_recurrence():
         assert worst < 1 << 46 and off <= B // 4, (worst, off)
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("params", [O.TOY_K2] + [p for p in O.TOY_SHAPES if p.N in (512, 1024, 4096)], ids=lambda p: p.name)
+def test_two_workgroups_per_cu_kernels_of_every_shape(params):
+    """Batches of 2 and 4 LWEs per CU (+ 3) on every shape that has a two-LWEs-per-CU kernel or takes more than one round
+    of its only kernel: the time-sliced priorities of blind_rotate_wide_kernel (BlindRotateArgs::fair_shift; a ticket per
+    hardware CU, parity through LDS) are on for these counts.  Decrypt-exact, per-LWE tables, and the first LWEs agree
+    with a small launch of the same ciphertexts within the noise model's 8 sigma."""
+    import fhestr
+    ks = keyset(params)
+    eng = gpu_engine(ks)
+    M = params.msg_mod * params.carry_mod
+    fs = [lambda x: (M - 1 - x), lambda x: (x + 1) % M]
+    ids = np.array([eng.upload_lut(ks.sk.generate_lookup_table(f)[0]) for f in fs], dtype=np.uint32)
+    for B in (2 * 256 + 3, 4 * 256 + 3):
+        rng = np.random.default_rng(B)
+        msgs = rng.integers(0, M, size=B)
+        sel = rng.integers(0, 2, size=B)
+        cts = ks.ck.encrypt_many(msgs, O.Rng(91, B))
+        got = eng.apply_lookup_table(cts, ids[sel])
+        want = np.where(sel == 0, M - 1 - msgs, (msgs + 1) % M)
+        assert np.array_equal(ks.ck.decrypt_many(got), want)
+        few = eng.apply_lookup_table(cts[:5], ids[sel[:5]])
+        tol = 8.0 * np.sqrt(2.0 * fhestr.noise_model(to_fhestr_params(params))["v_pbs"]) * 2.0**64
+        phase = lambda c: np.array([ks.ck.decrypt_plaintext(x) for x in c], dtype=np.uint64)
+        assert torus_distance(phase(got[:5]), phase(few)).max() < tol
