@@ -311,6 +311,13 @@ def rooflines(P, B, world, value, br_avg_ms, revision, log2_points, kernel="blin
         comp["valu_insts_per_wave_step"] = ctr["SQ_INSTS_VALU"] / (ctr["SQ_WAVES"] * n_steps)
         comp["lds_insts_per_wave_step"] = ctr["SQ_INSTS_LDS"] / (ctr["SQ_WAVES"] * n_steps)
         comp["counters_source"] = src
+        if concurrency > 1:
+            # rocprofv3 --pmc serialises dispatches: the fractions above are those of ONE launch running alone (one wave per
+            # SIMD for the two-LWEs-per-CU kernel).  Overlapped, `concurrency` launches put that many times the VALU-active
+            # cycles into one launch duration; the SIMD clock under load is not read here, so both ends are given.
+            active = 4.0 * ctr["SQ_ACTIVE_INST_VALU"] / (256 * 4)          # VALU-active cycles per SIMD and launch
+            comp["valu_issue_frac_note"] = "counters of a launch running alone (PMC passes serialise dispatches)"
+            comp["valu_busy_frac_overlapped_estimate"] = [concurrency * active / (br_avg_ms * 1e-3 * f) for f in (2.4e9, 2.1e9)]
     whole = {"bytes_per_pbs": pbs_bytes, "frac_of_peak": value * pbs_bytes / (world * HBM_PEAK_GBS * 1e9),
              "compulsory_bytes_per_pbs_at_this_batch": compulsory,
              "compulsory_frac_of_peak": value * compulsory / (world * HBM_PEAK_GBS * 1e9),
