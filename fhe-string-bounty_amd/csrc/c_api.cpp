@@ -376,6 +376,15 @@ int fhe_plan_pbs_signed(fhe_plan* p, uint32_t src, uint32_t lut, uint32_t* node)
     API_END
 }
 
+int fhe_plan_pbs_full_box(fhe_plan* p, uint32_t src, int all, uint32_t* node) {
+    API_BEGIN
+    PLAN_BUILDING(p); CHECK_PTR(node);
+    *node = p->c->pbs_full_box(src, all != 0);
+    if (p->c->failed()) return fail(p->c->take_error());
+    return 0;
+    API_END
+}
+
 int fhe_plan_set_owner_hint(fhe_plan* p, int rank) {
     API_BEGIN
     PLAN_BUILDING(p);

@@ -153,22 +153,74 @@ uint32_t Circuit::pbs(uint32_t id, uint32_t lut_id, bool signed_input) {
     return (uint32_t)nodes_.size() - 1;
 }
 
+uint32_t Circuit::pbs_full_box(uint32_t id, bool all) {
+    if (id >= nodes_.size()) { set_error("pbs_full_box: bad node id"); return 0; }
+    uint32_t src = id;
+    if (nodes_[id].kind != Node::LIN) src = lin({{id, 1}});
+    const Node& s = nodes_[src];
+    const int64_t T = (int64_t)total_modulus();
+    if (s.vmin < 0 || s.vmax > T) {
+        set_error("pbs_full_box: the sum must lie in [0, msg*carry], got [" + std::to_string(s.vmin) + ", " + std::to_string(s.vmax) + "]");
+        return 0;
+    }
+    if (s.terms.empty()) return trivial(all ? (int64_t)(s.cst == T) : (int64_t)(s.cst != 0));
+    max_pbs_input_noise_ = std::max(max_pbs_input_noise_, s.noise);
+    if (noise_budget_ > 0.0 && s.noise > noise_budget_) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "pbs: input noise %.1f nominal variances exceeds this parameter set's budget of %.1f",
+                 s.noise, noise_budget_);
+        set_error(buf);
+        return 0;
+    }
+    int& lut_id = full_box_lut_[all ? 1 : 0];
+    if (lut_id < 0) {
+        const uint64_t half_delta = ((1ull << 63) / (uint64_t)T) / 2;
+        std::vector<uint64_t> values((size_t)T), clear((size_t)T);
+        for (int64_t i = 0; i < T; i++) {
+            const bool plus = !all && i != 0;
+            values[(size_t)i] = plus ? half_delta : 0 - half_delta;
+            clear[(size_t)i] = plus ? 1 : 0;            // the logical result on [0, T); s = T gives 1 either way
+        }
+        std::vector<uint64_t> acc;
+        fill_accumulator_torus(p_, values.data(), acc);
+        lut_id = (int)lut_accs_.size();
+        lut_accs_.push_back(acc);
+        lut_tables_.push_back(clear);                   // not in lut_cache_: an ordinary table with these values is another accumulator
+    }
+    Node n;
+    n.kind = Node::PBS;
+    n.half = true;
+    n.src = src;
+    n.lut = (uint32_t)lut_id;
+    n.level = s.level + 1;
+    n.vmin = 0;
+    n.vmax = 1;
+    n.noise = 1.0;
+    n.owner = (int16_t)(owner_hint_ >= 0 ? owner_hint_ : owner_of(src));
+    nodes_.push_back(n);
+    n_pbs_++;
+    return (uint32_t)nodes_.size() - 1;
+}
+
 void Circuit::build_csr(Level& lv, const std::vector<uint32_t>& lin_nodes) {
     const uint64_t delta = (1ull << 63) / total_modulus();
     lv.off.assign(1, 0);
     lv.src.clear(); lv.coeff.clear(); lv.cst.clear();
     for (uint32_t id : lin_nodes) {
         const Node& s = nodes_[id];
+        // sources produced by pbs_full_box hold value - 1/2: their share of the constant is coeff * delta / 2
         if (s.kind == Node::LIN) {
+            int64_t halves = 0;
             for (const Term& t : s.terms) {
                 lv.src.push_back(nodes_[t.node].slot);
                 lv.coeff.push_back(t.coeff);
+                if (nodes_[t.node].half) halves += t.coeff;
             }
-            lv.cst.push_back((uint64_t)s.cst * delta);
+            lv.cst.push_back((uint64_t)s.cst * delta + (uint64_t)halves * (delta / 2));
         } else {
             lv.src.push_back(s.slot);
             lv.coeff.push_back(1);
-            lv.cst.push_back(0);
+            lv.cst.push_back(s.half ? delta / 2 : 0);
         }
         lv.off.push_back((uint32_t)lv.src.size());
     }

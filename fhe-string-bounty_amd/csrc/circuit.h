@@ -48,6 +48,7 @@ struct Term {
 struct Node {
     enum Kind : uint8_t { INPUT, LIN, PBS } kind;
     bool exported = false;     // PBS: consumed by another rank or by the outputs -> part of the all-gather
+    bool half = false;         // PBS (pbs_full_box): the ciphertext holds value - 1/2; every consumer adds coeff * delta / 2
     int16_t owner = -1;        // PBS: rank that runs it (-1 while building = decided at finalize)
     uint32_t level = 0;        // 0 for inputs; PBS: 1 + max level of deps; LIN: max level of deps
     int64_t vmin = 0, vmax = 0;   // clear value range (message+carry space; vmin < 0 = reaches the padding bit)
@@ -78,6 +79,14 @@ public:
     // apply_lookup_table.  signed_input: the value may be negative, i.e. the torus value uses the
     // padding bit and the table is read through its negacyclic extension f(x - T) = -f(x).
     uint32_t pbs(uint32_t node, uint32_t lut, bool signed_input = false);
+    // Reduction of exactly msg*carry = T bits in ONE lookup (the reference's are_all_comparisons_block_true /
+    // is_at_least_one_comparisons_block_true take T - 1 per lookup, scalar_comparison.rs:147-233): the sum s lies in
+    // [0, T], and s = T is the padding bit, read as -f(0) by the negacyclic table.  With f = g - 1/2 that is consistent:
+    //   any (s != 0):  f(0) = -1/2, f(1..T-1) = +1/2  =>  f(T) = +1/2;      all (s == T):  f = -1/2 on [0, T)  =>  f(T) = +1/2
+    // The table's entries are -/+ delta/2 (not multiples of delta), the missing +1/2 is added by whoever reads the result
+    // (Node::half: folded into the constant of every linear combination at finalize) -- no extra operation, the same
+    // output noise, the same decision margin of delta/2 at the input.  `node` must be a sum with value range [0, T].
+    uint32_t pbs_full_box(uint32_t node, bool all);
     // generate_lookup_table with a cache keyed on the table contents (mod.rs:383-399)
     uint32_t lut(const std::vector<uint64_t>& table);
     template <class F>
@@ -168,6 +177,7 @@ private:
     Level out_;
     uint32_t n_inputs_ = 0, n_pbs_ = 0, pool_slots_ = 0, world_ = 1, build_world_ = 1;
     int owner_hint_ = -1;
+    int full_box_lut_[2] = {-1, -1};   // plan-local ids of the two -/+ delta/2 tables ([0] any, [1] all)
     double noise_budget_ = 0.0, max_pbs_input_noise_ = 0.0;
     std::string error_;
     void* d_meta_ = nullptr;

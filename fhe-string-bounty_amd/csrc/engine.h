@@ -38,6 +38,8 @@ struct BrVariant;
 
 // fill_accumulator: shortint/engine/mod.rs:72-128 (host side, no device needed)
 uint64_t fill_accumulator(const fhe_params_t& p, const uint64_t* table, std::vector<uint64_t>& acc);
+// the same from torus values per box (tables whose entries are not multiples of delta: Circuit::pbs_full_box)
+void fill_accumulator_torus(const fhe_params_t& p, const uint64_t* box_values, std::vector<uint64_t>& acc);
 
 struct Engine {
     std::recursive_mutex mu;      // taken by every C ABI entry point that touches this engine (c_api.cpp, LOCK_ENGINE)

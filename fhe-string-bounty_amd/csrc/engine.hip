@@ -595,23 +595,31 @@ int Engine::install_keys(uint64_t* d_ksk_std, uint64_t* d_std) {
     return 0;
 }
 
-// fill_accumulator: shortint/engine/mod.rs:72-128
-uint64_t fill_accumulator(const fhe_params_t& p, const uint64_t* table, std::vector<uint64_t>& acc) {
+// fill_accumulator: shortint/engine/mod.rs:72-128.  box_values[i] = the torus value the table returns on box i
+void fill_accumulator_torus(const fhe_params_t& p, const uint64_t* box_values, std::vector<uint64_t>& acc) {
     const uint32_t N = p.N, k = p.k;
     acc.assign((size_t)(k + 1) * N, 0);
     uint64_t* body = acc.data() + (size_t)k * N;
     const uint32_t modulus_sup = p.msg_mod * p.carry_mod;
     const uint32_t box = N / modulus_sup;
-    const uint64_t delta = (1ull << 63) / modulus_sup;
-    uint64_t maxv = 0;
     std::vector<uint64_t> tmp(N);
-    for (uint32_t i = 0; i < modulus_sup; i++) {
-        maxv = table[i] > maxv ? table[i] : maxv;
-        for (uint32_t j = 0; j < box; j++) tmp[(size_t)i * box + j] = table[i] * delta;
-    }
+    for (uint32_t i = 0; i < modulus_sup; i++)
+        for (uint32_t j = 0; j < box; j++) tmp[(size_t)i * box + j] = box_values[i];
     const uint32_t half = box / 2;
     for (uint32_t j = 0; j < half; j++) tmp[j] = 0 - tmp[j];
     for (uint32_t j = 0; j < N; j++) body[j] = tmp[(j + half) % N];   // rotate_left(half)
+}
+
+uint64_t fill_accumulator(const fhe_params_t& p, const uint64_t* table, std::vector<uint64_t>& acc) {
+    const uint32_t modulus_sup = p.msg_mod * p.carry_mod;
+    const uint64_t delta = (1ull << 63) / modulus_sup;
+    uint64_t maxv = 0;
+    std::vector<uint64_t> values(modulus_sup);
+    for (uint32_t i = 0; i < modulus_sup; i++) {
+        maxv = table[i] > maxv ? table[i] : maxv;
+        values[i] = table[i] * delta;
+    }
+    fill_accumulator_torus(p, values.data(), acc);
     return maxv;
 }
 

@@ -85,6 +85,7 @@ public:
     // Encrypted-vs-encrypted comparisons: true = compare two blocks per PBS (see packed_pair_eq),
     // false = the reference's one-bivariate-PBS-per-block shape (comparison.rs:10-33).
     bool packed_compare = true;
+    bool full_box_reduce = true;       // reductions take T bits per lookup (false: T - 1, the reference's chunks)
 
     Str input_string(uint32_t cap) {
         Str s;
@@ -101,14 +102,18 @@ public:
     // are_all_comparisons_block_true (scalar_comparison.rs:147-191) / is_at_least_one_comparisons_block_true
     // (scalar_comparison.rs:200-233) on one rank: chunks of up to msg*carry - 1 bits (fewer if the
     // noise budget says so) are summed and sent through `x == chunk_len` / `x != 0`, repeated to one bit
+    // Default (not the reference-shaped plans): chunks of T bits where that saves a lookup level -- the sum T is the
+    // padding bit, answered consistently by a table of -/+ delta/2 (Circuit::pbs_full_box).  AND over a 16-char pattern
+    // and OR over up to 256 offsets then take one level less each (PARAM_MESSAGE_2_CARRY_2: contains 16-in-256 7 -> 5 levels).
     uint32_t reduce_local(std::vector<uint32_t> bits, bool all) {
         const uint32_t nz = c.lut_fn([](uint64_t x) { return (uint64_t)(x != 0); });
         while (bits.size() > 1) {
             std::vector<Term> terms;
             for (uint32_t b : bits) terms.push_back({b, 1});
             std::vector<uint32_t> next;
-            for (const auto& g : term_groups(terms, T - 1)) {
+            for (const auto& g : term_groups(terms, full_box_reduce ? T : T - 1)) {
                 const size_t len = g.size();
+                if (len == T) { next.push_back(c.pbs_full_box(c.lin(g), all)); continue; }
                 const uint32_t l = all ? c.lut_fn([len](uint64_t x) { return (uint64_t)(x == len); }) : nz;
                 next.push_back(c.pbs(c.lin(g), l));
             }
@@ -1059,6 +1064,7 @@ int build_string_op(Circuit& c, const std::string& op, uint32_t a_cap, uint32_t 
         const std::string t(tail);
         if (op_name.size() > t.size() && op_name.compare(op_name.size() - t.size(), t.size(), t) == 0) {
             s.packed_compare = false;          // the reference's block-by-block circuit shape
+            s.full_box_reduce = false;         // ... and its chunks of T - 1 comparison bits
             op_name = op_name.substr(0, op_name.size() - t.size()) + (t == "_reference_clear" ? "_clear" : "");
             break;
         }

@@ -148,7 +148,7 @@ EXPORTS = [
     "fhe_plan_run", "fhe_plan_run_level_rank_dev", "fhe_plan_gather_outputs_dev", "fhe_str_plan_create",
     "fhe_plan_level_rank_info", "fhe_plan_noise_info", "fhe_noise_model", "fhe_noise_model_is_calibrated", "fhe_plan_set_noise_budget",
     "fhe_host_alloc", "fhe_host_free",
-    "fhe_plan_pbs_signed", "fhe_plan_set_owner_hint",
+    "fhe_plan_pbs_signed", "fhe_plan_pbs_full_box", "fhe_plan_set_owner_hint",
     "fhe_str_to_upper", "fhe_str_to_lower", "fhe_plan_create_offline", "fhe_str_plan_create_offline",
     "fhe_str_trim_start", "fhe_str_trim_end", "fhe_str_strip", "fhe_str_replace", "fhe_str_replace_clear",
     "fhe_plan_lut_count", "fhe_plan_export_lut", "fhe_engine_set_stream", "fhe_engine_reset_stream",
@@ -250,6 +250,7 @@ def lib() -> C.CDLL:
     sig("fhe_host_free", vp)
     sig("fhe_plan_set_noise_budget", vp, C.c_double)
     sig("fhe_plan_pbs_signed", vp, u32, u32, C.POINTER(u32))
+    sig("fhe_plan_pbs_full_box", vp, u32, C.c_int, C.POINTER(u32))
     sig("fhe_plan_set_owner_hint", vp, i32)
     sig("fhe_plan_gather_outputs_dev", vp, vp, vp)
     sig("fhe_str_plan_create", vp, C.c_char_p, u32, u32, vp, u32, u32, C.POINTER(vp))
@@ -714,6 +715,12 @@ class Plan:
         """apply_lookup_table; signed=True declares that the input may be negative (padding bit in use)."""
         out = C.c_uint32()
         _check((lib().fhe_plan_pbs_signed if signed else lib().fhe_plan_pbs)(self._h, src, lut, C.byref(out)))
+        return out.value
+
+    def pbs_full_box(self, src: int, all: bool) -> int:
+        """msg*carry bits reduced in one lookup: (sum == msg*carry) if all else (sum != 0); see include/fhestr.h."""
+        out = C.c_uint32()
+        _check(lib().fhe_plan_pbs_full_box(self._h, src, int(bool(all)), C.byref(out)))
         return out.value
 
     def set_owner_hint(self, rank: int):

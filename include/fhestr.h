@@ -190,6 +190,12 @@ int fhe_plan_pbs(fhe_plan *plan, uint32_t src, uint32_t lut, uint32_t *node); /*
  * f(x - msg*carry) = -f(x).  Both refuse inputs above the parameter set's noise budget (in units of one
  * nominal ciphertext variance; MaxNoiseLevel::validate, shortint/ciphertext/mod.rs:28-55). */
 int fhe_plan_pbs_signed(fhe_plan *plan, uint32_t src, uint32_t lut, uint32_t *node);
+/* Reduction of msg*carry = T bits in one lookup: `src` is a sum with value range [0, T]; the result is the bit
+ * (sum == T) if `all`, else (sum != 0).  The reference's are_all_comparisons_block_true /
+ * is_at_least_one_comparisons_block_true (integer/server_key/radix_parallel/scalar_comparison.rs:147-233) take T - 1
+ * bits per lookup; sum = T is the padding bit, which a table with entries -/+ delta/2 answers consistently (csrc/circuit.h).
+ * One level less for AND over a 16-char pattern and OR over up to 256 offsets under PARAM_MESSAGE_2_CARRY_2. */
+int fhe_plan_pbs_full_box(fhe_plan *plan, uint32_t src, int all, uint32_t *node);
 int fhe_plan_set_noise_budget(fhe_plan *plan, double budget);   /* <= 0: no check */
 /* PBS nodes created from now on run on `rank` (-1: automatic).  Used with world > 1 to keep a slice of
  * the work and its first reduction levels on one GPU. */

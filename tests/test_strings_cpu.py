@@ -137,9 +137,15 @@ def test_plan_shapes_match_survey_counts():
     info = _plan("eq_reference", 256, 256).info()
     assert (info["n_pbs"], info["n_levels"], info["n_inputs"], info["n_outputs"]) == (1099, 4, 2048, 1)
     # default: two blocks per PBS through the padding bit (fhe_string.cpp: packed_pair_eq)
-    assert _plan("eq", 256, 256).info()["n_pbs"] == 512 + 35 + 3 + 1
+    # ... and reductions of 16 bits per lookup (Circuit::pbs_full_box) instead of the reference's 15
+    assert _plan("eq", 256, 256).info()["n_pbs"] == 512 + 32 + 2 + 1
     info = _plan("eq_clear", 256, 0, b"x" * 200).info()
-    assert (info["n_pbs"], info["n_levels"]) == (551, 4)
+    assert (info["n_pbs"], info["n_levels"]) == (547, 4)
+    # contains, 16-char encrypted pattern in 256 chars: AND over the 16 chars and OR over the 241 offsets lose a level each
+    plan = _plan("contains", 256, 16)
+    assert [plan.level_info(l)["jobs"] for l in range(plan.info()["n_levels"])] == [7968, 3976, 256, 16, 1]
+    plan = _plan("contains_reference", 256, 16)
+    assert [plan.level_info(l)["jobs"] for l in range(plan.info()["n_levels"])] == [15920, 3991, 497, 256, 18, 2, 1]
     lv = [_plan("eq_reference", 256, 256).level_info(l)["jobs"] for l in range(4)]
     assert lv == [1024, 69, 5, 1]
 
@@ -494,3 +500,41 @@ def test_clear_patterns_by_classes_offline_plan_vs_python(hay, pat):
         plan = _plan4("replace_clear", cap, 0, pat + to)
         got = fhestr.blocks_to_string(P, ks.ck.decrypt_many(run_with_oracle(plan, enc, ks.sk)))
         assert got == hay.replace(pat, to)
+
+
+def test_full_box_reduction_every_sum_and_every_kind_of_consumer(toy_k1):
+    """Circuit::pbs_full_box (fhe_plan_pbs_full_box): T = msg*carry bits in one lookup.  Every sum 0 .. T through `all`
+    and `any`, the result read directly, negated (1 - b), summed with its twin and fed to another lookup -- the +1/2
+    the consumers owe (Node::half) must arrive in every position.  Oracle-executed (bit-exact integer bookkeeping:
+    a wrong constant would shift the next lookup by half a box)."""
+    import fhestr
+    P = to_fhestr_params(O.TOY_K1)
+    T = P.msg_mod * P.carry_mod
+    plan = fhestr.Plan(None, params=P)
+    bits = [plan.input(1) for _ in range(T)]
+    total = plan.lin([(b, 1) for b in bits])
+    all_b = plan.pbs_full_box(total, True)
+    any_b = plan.pbs_full_box(total, False)
+    ident = plan.lut(lambda i: i)
+    plan.output(all_b)
+    plan.output(any_b)
+    plan.output(plan.lin([(all_b, -1)], 1))                              # not all
+    plan.output(plan.lin([(all_b, 2), (any_b, 3)], 1))                   # 1 + 2 all + 3 any
+    plan.output(plan.pbs(plan.lin([(all_b, 1), (any_b, 1), (bits[0], 1)]), ident))
+    with pytest.raises(fhestr.FheError, match="must lie in"):
+        plan.pbs_full_box(plan.lin([(b, 1) for b in bits] + [(bits[0], 1)]), True)     # up to T + 1
+    plan.finalize(1)
+    assert plan.info()["n_levels"] == 2
+    for s in range(T + 1):
+        values = [1] * s + [0] * (T - s)
+        values = values[::-1] if s % 2 else values
+        out = toy_k1.ck.decrypt_many(run_with_oracle(plan, toy_k1.ck.encrypt_many(values), toy_k1.sk)).tolist()
+        a, o = int(s == T), int(s != 0)
+        assert out == [a, o, 1 - a, 1 + 2 * a + 3 * o, a + o + values[0]], (s, out)
+    # trivial inputs fold at build time
+    plan = fhestr.Plan(None, params=P)
+    x = plan.input(1)
+    t = plan.pbs_full_box(plan.lin([], T), True)
+    plan.output(plan.lin([(x, 1), (t, 1)]))
+    plan.finalize(1)
+    assert plan.info()["n_pbs"] == 0
