@@ -447,7 +447,7 @@ public:
     // ---- find: (found, index digits) of the first match ----
     // prefix_any[o] = OR_{o' <= o} bits[o'] through a blocked scan (fan-in T-1 per PBS)
     std::vector<uint32_t> prefix_or(const std::vector<uint32_t>& bits) {
-        const uint32_t F = T - 1;
+        const uint32_t F = full_box_reduce ? T : T - 1;        // a run of T bits: Circuit::pbs_full_box
         const uint32_t nz = c.lut_fn([](uint64_t x) { return (uint64_t)(x != 0); });
         const size_t n = bits.size();
         if (n <= 1) return bits;
@@ -456,7 +456,7 @@ public:
             std::vector<Term> run;
             for (size_t j = b; j < std::min(n, b + F); j++) {
                 run.push_back({bits[j], 1});
-                within[j] = run.size() == 1 ? bits[j] : c.pbs(c.lin(run), nz);
+                within[j] = run.size() == 1 ? bits[j] : run.size() == T ? c.pbs_full_box(c.lin(run), false) : c.pbs(c.lin(run), nz);
             }
             block_tot.push_back(within[std::min(n, b + F) - 1]);
         }

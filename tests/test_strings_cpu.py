@@ -538,3 +538,25 @@ def test_full_box_reduction_every_sum_and_every_kind_of_consumer(toy_k1):
     plan.output(plan.lin([(x, 1), (t, 1)]))
     plan.finalize(1)
     assert plan.info()["n_pbs"] == 0
+
+
+@pytest.mark.parametrize("s,pat", [(b"xxxxxxxxxxxxxxxxxab", b"ab"), (b"abxxxxxxxxxxxxxxxab", b"ab"), (b"xxxxxxxxxxxxxxxxxxx", b"ab"),
+                                   (b"xxxxxxxxxxxxxxxab", b"ab"), (b"", b"a")])
+def test_find_contains_over_more_than_16_offsets(toy_k1, s, pat):
+    """20-char haystack, 2-char pattern: 19 .. 21 candidate offsets, so the OR over the offsets and find's prefix scan
+    meet runs of exactly T = 16 bits (Circuit::pbs_full_box) next to shorter ones.  Oracle-executed vs Python."""
+    import fhestr
+    P = to_fhestr_params(O.TOY_K1)
+    inputs = np.concatenate([_enc(toy_k1, s, 20), _enc(toy_k1, pat, 2)])
+    for op in ("contains", "find", "rfind", "ends_with"):
+        plan = fhestr.Plan.string_op(None, op, 20, 2, None, 1, params=P)
+        out = toy_k1.ck.decrypt_many(run_with_oracle(plan, inputs, toy_k1.sk)).tolist()
+        if op == "contains":
+            assert out == [int(pat in s)], (op, out)
+        elif op == "ends_with":
+            assert out == [int(s.endswith(pat))], (op, out)
+        else:
+            idx = s.find(pat) if op == "find" else s.rfind(pat)
+            digits = out[1:]
+            got = sum(d * P.msg_mod**i for i, d in enumerate(digits))
+            assert out[0] == int(idx >= 0) and (idx < 0 or got == idx), (op, out, idx)
