@@ -45,7 +45,8 @@ def check(name, got, want, ctx):
 
 
 for case in range(N_CASES):
-    cap = int(rng.choice([2, 3, 4, 6, 8] if p.msg_mod == 4 else [3, 4, 6, 8, 12]))
+    # 20 / 24: more than msg*carry = 16 candidate offsets, so reductions and prefix scans meet runs of exactly 16 bits
+    cap = int(rng.choice([2, 3, 4, 6, 8, 20] if p.msg_mod == 4 else [3, 4, 6, 8, 12, 24]))
     a = rand_str(cap)
     # patterns: often substrings of a so that positive cases are frequent
     if len(a) and rng.random() < 0.6:
