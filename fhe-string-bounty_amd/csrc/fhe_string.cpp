@@ -475,13 +475,38 @@ public:
                            bool from_end = false) {
         std::vector<uint32_t> match(match_in);
         if (from_end) std::reverse(match.begin(), match.end());
-        std::vector<uint32_t> pre = prefix_or(match);
-        const uint32_t found = pre.back();
-        // first[o] = match[o] AND NOT pre[o-1]  ==  (match[o] + 2*pre[o-1]) == 1
+        // first[o] = match[o] AND no match before o.  "Before o" = earlier in o's block of the scan (prefix inside the
+        // block) or in an earlier block (prefix over the block totals): the two are fed to the lookup side by side,
+        // (match[o] + 2 * before_in_block + 4 * before_in_earlier_blocks) == 1, so the full prefix is never materialised
+        // (one lookup level and n lookups less than prefix_or + a test against it).
         const uint32_t first_lut = c.lut_fn([](uint64_t x) { return (uint64_t)(x == 1); });
-        std::vector<uint32_t> first(match.size());
-        for (size_t o = 0; o < match.size(); o++)
-            first[o] = o == 0 ? match[0] : c.pbs(c.lin({{match[o], 1}, {pre[o - 1], 2}}), first_lut);
+        const uint32_t nz = c.lut_fn([](uint64_t x) { return (uint64_t)(x != 0); });
+        const uint32_t Fb = full_box_reduce ? T : T - 1;
+        const size_t n = match.size();
+        if (n == 0) {                                   // no candidate offset at all: not found, index 0
+            out.push_back(c.trivial(0));
+            for (uint32_t d = 0; d < n_digits; d++) out.push_back(c.trivial(0));
+            return;
+        }
+        std::vector<uint32_t> within(n), block_tot;
+        for (size_t b = 0; b < n; b += Fb) {
+            std::vector<Term> run;
+            for (size_t j = b; j < std::min(n, b + Fb); j++) {
+                run.push_back({match[j], 1});
+                within[j] = run.size() == 1 ? match[j] : run.size() == T ? c.pbs_full_box(c.lin(run), false) : c.pbs(c.lin(run), nz);
+            }
+            block_tot.push_back(within[std::min(n, b + Fb) - 1]);
+        }
+        const std::vector<uint32_t> block_pre = prefix_or(block_tot);      // inclusive, over the blocks
+        const uint32_t found = block_pre.back();
+        std::vector<uint32_t> first(n);
+        for (size_t o = 0; o < n; o++) {
+            const size_t b = o / Fb, r = o % Fb;
+            std::vector<Term> t{{match[o], 1}};
+            if (r > 0) t.push_back({within[o - 1], 2});
+            if (b > 0) t.push_back({block_pre[b - 1], 4});
+            first[o] = t.size() == 1 ? match[o] : c.pbs(c.lin(t), first_lut);
+        }
         if (from_end) std::reverse(first.begin(), first.end());   // one-hot vector back on the original offsets
         out.push_back(found);
         const uint32_t F = T - 1;
