@@ -5,17 +5,17 @@ print("value", round(d["value"]), "PBS/s; ms/step", round(d["ms_per_step"], 3), 
       "; ks-shadow", round(d["pipelined_keyswitch_only"]["pbs_per_s_per_gpu"]))
 print("sweep", d.get("batch_sweep_pbs_per_s"))
 print("roofline", {k: d["roofline"][k] for k in ("bound", "achieved", "frac", "avg_launch_ms", "kernel")})
-for k, v in d.get("string_ops", {}).items():
+for k, v in (d.get("string_ops") or {}).items():
     if isinstance(v, dict):
         print(f"  {k}: {v['ms_per_op']:.2f} ms resident, {v['ms_per_op_inputs_from_host']:.2f} ms from host, {v['n_pbs']} PBS, correct {v['correct']}")
-p = d.get("p44", {})
+p = d.get("p44") or {}
 if p:
     print("p44", round(p["pbs_per_s"], 1), "PBS/s;", p["kernel_ms"], p.get("small_batch_kernel_ms"))
     print("p44 roofline", p.get("roofline", {}).get("frac"))
     for k, v in p.get("string_ops", {}).items():
         print("  p44", k, {a: (round(b, 1) if isinstance(b, float) else b) for a, b in v.items()})
-mb = d.get("multi_bit_pbs", {})
+mb = d.get("multi_bit_pbs") or {}
 for g, v in mb.items():
     print(" ", g, round(v["pbs_per_s"]), "PBS/s; 1 LWE", round(v["batch_1"]["ms_per_step"], 3), "ms; eq", round(v["fhestring_eq_256_ms"], 2), "ms")
-c = d.get("cpu_baseline", {})
+c = d.get("cpu_baseline") or {}
 print("cpu", c.get("value"), c.get("cores"), c.get("pbs_per_s_by_threads"))
