@@ -524,8 +524,8 @@ def main():
     # kernel); mode 1 (keyswitch in the shadow of the previous blind rotation, the round-2 headline) and the serial
     # figure are reported next to it.
     eng.set_pipeline(0 if args.serial else 2)
-    # Untimed, before the W warm-up steps the caller asked for: enough steps that the part has ramped its clock back after
-    # the idle seconds of key generation and encryption (profiles/r03_after_idle.txt: tens of ms at 12-16 % less) --
+    # Untimed, before the W warm-up steps the caller asked for: enough steps that the slowdown that follows an idle GPU is over after
+    # the idle seconds of key generation and encryption (profiles/r03_after_idle.txt: launches run 12-16 % slower for tens of ms) --
     # together with W at least 40 steps; reported as `prewarm_steps`.
     prewarm = max(0, 40 - args.warmup)
     for _ in range(prewarm + args.warmup):
@@ -630,7 +630,7 @@ def main():
             big_out = torch.empty_like(big_in)
             torch.cuda.synchronize()
             # two untimed launches first: a launch that follows the nearly idle GPU of the small batches runs 12-16 % slower
-            # while the part ramps its clock back (profiles/r03_after_idle.txt)
+            # for tens of ms (profiles/r03_after_idle.txt)
             for it in range(5):
                 if it == 2:
                     eng.synchronize()
