@@ -524,7 +524,7 @@ def main():
     # kernel); mode 1 (keyswitch in the shadow of the previous blind rotation, the round-2 headline) and the serial
     # figure are reported next to it.
     eng.set_pipeline(0 if args.serial else 2)
-    # Untimed, before the W warm-up steps the caller asked for: enough steps that the slowdown that follows an idle GPU is over after
+    # Untimed, before the W warm-up steps the caller asked for: enough steps that the clock ramp that follows an idle GPU is over after
     # the idle seconds of key generation and encryption (profiles/r03_after_idle.txt: launches run 12-16 % slower for tens of ms) --
     # together with W at least 40 steps; reported as `prewarm_steps`.
     prewarm = max(0, 40 - args.warmup)
