@@ -149,6 +149,14 @@ int fhe_engine_set_cluster_mode(fhe_engine* eng, int mode, uint32_t max_batch) {
     API_END
 }
 
+int fhe_engine_set_keep_busy(fhe_engine* eng, int on) {
+    API_BEGIN
+    CHECK_PTR(eng); LOCK_ENGINE(eng);
+    eng->impl->keep_busy = on != 0;
+    return 0;
+    API_END
+}
+
 int fhe_engine_cluster_info(fhe_engine* eng, uint32_t* clusters) {
     API_BEGIN
     CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(clusters);

@@ -64,6 +64,7 @@ struct Engine {
     static constexpr int OVL_MAX = 4;
     int ovl_streams = 2;
     uint32_t wide_fair_shift = 13;           // two-LWEs-per-CU kernel: log2 ticks (100 MHz) of the priority time slice, 0 = off (FHESTR_WIDE_FAIR)
+    bool keep_busy = false;                  // small launches carry replicas on the idle CUs (fhe_engine_set_keep_busy, FHESTR_KEEP_BUSY)
     hipStream_t ovl_stream[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ovl_done[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};
     const void* ovl_in[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};

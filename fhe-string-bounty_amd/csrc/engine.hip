@@ -272,6 +272,7 @@ int Engine::create(const fhe_params_t& p, int device, Engine** out) {
     e->variant = v;
     e->variant_large = v;
     if (const char* m = getenv("FHESTR_WIDE_FAIR")) e->wide_fair_shift = (uint32_t)std::min(20, std::max(0, atoi(m)));
+    if (const char* m = getenv("FHESTR_KEEP_BUSY")) e->keep_busy = atoi(m) != 0;
     if (const char* m = getenv("FHESTR_OVERLAP_STREAMS")) e->ovl_streams = std::min((int)Engine::OVL_MAX, std::max(2, atoi(m)));
     if (const char* m = getenv("FHESTR_KS_MFMA")) e->ks_mfma_enabled = atoi(m) != 0;
     if (const char* m = getenv("FHESTR_CLUSTER_SPIN_LIMIT")) e->cluster_spin_limit = (uint32_t)std::max(64, atoi(m));
@@ -840,7 +841,12 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
                                 v->lds_bytes + (size_t)p.n * v->lds_per_n, stream));
         return 0;
     }
-    HIP_TRY(hipLaunchKernel(v->rotate_fn, dim3(count), dim3(v->threads), args,
+    // keep-busy mode (fhe_engine_set_keep_busy): a launch that would leave more than half of the CUs idle carries replicas of
+    // its workgroups on them (they recompute and store nothing) -- the part then keeps its clock for the large launch that
+    // follows (2.22 -> 2.39 GHz over 14 ms otherwise, profiles/r03_after_idle.txt), at the price of the energy
+    uint32_t grid = count;
+    if (keep_busy && !v->wide && !v->large && count * 2 <= (uint32_t)cu_count) grid = count * ((uint32_t)cu_count / count);
+    HIP_TRY(hipLaunchKernel(v->rotate_fn, dim3(grid), dim3(v->threads), args,
                             v->lds_bytes + (size_t)p.n * v->lds_per_n, stream));
     return 0;
 }

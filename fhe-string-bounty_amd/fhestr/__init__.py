@@ -125,7 +125,7 @@ _lib = None
 EXPORTS = [
     "fhe_last_error", "fhe_kernel_revision", "fhe_engine_create", "fhe_engine_destroy", "fhe_engine_params",
     "fhe_engine_load_keys", "fhe_engine_generate_keys", "fhe_engine_stream", "fhe_engine_synchronize", "fhe_engine_set_variant",
-    "fhe_engine_set_multibit_combine_max", "fhe_engine_set_cluster_mode", "fhe_engine_pipeline_input_event", "fhe_engine_cluster_info", "fhe_engine_load_seeded_keys", "fhe_engine_set_pipeline",
+    "fhe_engine_set_multibit_combine_max", "fhe_engine_set_cluster_mode", "fhe_engine_set_keep_busy", "fhe_engine_pipeline_input_event", "fhe_engine_cluster_info", "fhe_engine_load_seeded_keys", "fhe_engine_set_pipeline",
     "fhe_lut_generate", "fhe_lut_upload", "fhe_lut_download", "fhe_lut_count",
     "fhe_keyswitch_batch", "fhe_pbs_batch", "fhe_ks_pbs_batch", "fhe_ks_pbs_batch_dev", "fhe_pbs_ks_batch",
     "fhe_lwe_lincomb_batch", "fhe_last_kernel_ms", "fhe_kernel_times",
@@ -202,6 +202,7 @@ def lib() -> C.CDLL:
     sig("fhe_engine_set_multibit_combine_max", vp, u32)
     sig("fhe_engine_set_pipeline", vp, i32)
     sig("fhe_engine_set_cluster_mode", vp, i32, u32)
+    sig("fhe_engine_set_keep_busy", vp, C.c_int)
     sig("fhe_engine_cluster_info", vp, C.POINTER(u32))
     sig("fhe_engine_load_seeded_keys", vp, vp, vp, vp, vp, vp, vp)
     sig("fhe_engine_expand_seeded_lwe", vp, vp, vp, u32, vp, vp)
@@ -403,6 +404,10 @@ class Engine:
         """The next pipelined apply_lookup_table_dev call's keyswitch waits for this hipEvent_t (e.g.
         torch.cuda.Event().cuda_event after .record()); see fhe_engine_pipeline_input_event."""
         _check(lib().fhe_engine_pipeline_input_event(self._h, C.c_void_p(hip_event)))
+
+    def set_keep_busy(self, on: bool):
+        """Small launches carry replicas on the idle CUs so the GPU keeps its clock for the next large one (include/fhestr.h)."""
+        _check(lib().fhe_engine_set_keep_busy(self.handle, int(bool(on))))
 
     def set_cluster_mode(self, mode: int, max_batch: int = 0xFFFFFFFF):
         """N >= 16384: several CUs per LWE (-1 automatic, 0 never, 1 always; include/fhestr.h)."""

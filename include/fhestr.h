@@ -117,6 +117,13 @@ int fhe_engine_set_multibit_combine_max(fhe_engine *eng, uint32_t max_batch);
  * LWE through an HBM workspace), 1 always; max_batch: in automatic mode, batches above it take the one-workgroup
  * kernel.  Both kernels read the same Fourier key and give decrypt-identical results. */
 int fhe_engine_set_cluster_mode(fhe_engine *eng, int mode, uint32_t max_batch);
+/* Latency knob for dependent chains of small batches (the trailing levels of a string comparison): with `on`, a
+ * blind-rotation launch that would leave more than half of the compute units idle carries replicas of its workgroups
+ * on them (they recompute an LWE of the batch and store nothing).  Results are unchanged; the part keeps drawing power
+ * and therefore keeps its clock for the large launch that follows -- otherwise that launch starts 7 % low in shader
+ * clock and needs about 14 ms to ramp back (profiles/r03_after_idle.txt).  Costs the energy of the replicas; off by
+ * default (FHESTR_KEEP_BUSY=1 turns it on at engine creation).  No counterpart in the reference. */
+int fhe_engine_set_keep_busy(fhe_engine *eng, int on);
 /* After a synchronisation: clusters the last cluster launch formed (0 if none ran). */
 int fhe_engine_cluster_info(fhe_engine *eng, uint32_t *clusters);
 

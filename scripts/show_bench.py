@@ -7,7 +7,8 @@ print("sweep", d.get("batch_sweep_pbs_per_s"))
 print("roofline", {k: d["roofline"][k] for k in ("bound", "achieved", "frac", "avg_launch_ms", "kernel")})
 for k, v in (d.get("string_ops") or {}).items():
     if isinstance(v, dict):
-        print(f"  {k}: {v['ms_per_op']:.2f} ms resident, {v['ms_per_op_inputs_from_host']:.2f} ms from host, {v['n_pbs']} PBS, correct {v['correct']}")
+        host = v.get('ms_per_op_inputs_from_host')
+        print(f"  {k}: {v['ms_per_op']:.2f} ms resident, " + (f"{host:.2f} ms from host, " if host else "") + f"{v['n_pbs']} PBS, correct {v['correct']}")
 p = d.get("p44") or {}
 if p:
     print("p44", round(p["pbs_per_s"], 1), "PBS/s;", p["kernel_ms"], p.get("small_batch_kernel_ms"))

@@ -691,3 +691,29 @@ def test_two_workgroups_per_cu_kernels_of_every_shape(params):
         tol = 8.0 * np.sqrt(2.0 * fhestr.noise_model(to_fhestr_params(params))["v_pbs"]) * 2.0**64
         phase = lambda c: np.array([ks.ck.decrypt_plaintext(x) for x in c], dtype=np.uint64)
         assert torus_distance(phase(got[:5]), phase(few)).max() < tol
+
+
+@pytest.mark.gpu
+def test_keep_busy_replicas_change_nothing(p22):
+    """fhe_engine_set_keep_busy: launches of at most half the CUs' worth of LWEs carry replica workgroups that store
+    nothing -- outputs are bit-identical to the plain launch (same kernel, same inputs), for 1, 3, 35 and 128 LWEs, and
+    a 129-LWE launch (no room for replicas) is untouched."""
+    ks = p22
+    eng = gpu_engine(ks)
+    M = ks.params.msg_mod * ks.params.carry_mod
+    lut, _ = ks.sk.generate_lookup_table(lambda x: (x + 5) % M)
+    lut_id = eng.upload_lut(lut)
+    rng = np.random.default_rng(3)
+    try:
+        for B in (1, 3, 35, 128, 129):
+            msgs = rng.integers(0, M, size=B)
+            cts = ks.ck.encrypt_many(msgs, O.Rng(41, B))
+            idx = np.full(B, lut_id, dtype=np.uint32)
+            eng.set_keep_busy(False)
+            plain = eng.apply_lookup_table(cts, idx)
+            eng.set_keep_busy(True)
+            busy = eng.apply_lookup_table(cts, idx)
+            assert np.array_equal(plain, busy), B
+            assert np.array_equal(ks.ck.decrypt_many(busy), (msgs + 5) % M)
+    finally:
+        eng.set_keep_busy(False)
