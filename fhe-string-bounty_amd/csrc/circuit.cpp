@@ -154,16 +154,24 @@ uint32_t Circuit::pbs(uint32_t id, uint32_t lut_id, bool signed_input) {
 }
 
 uint32_t Circuit::pbs_full_box(uint32_t id, bool all) {
-    if (id >= nodes_.size()) { set_error("pbs_full_box: bad node id"); return 0; }
+    std::vector<uint8_t> g(total_modulus());
+    for (size_t i = 0; i < g.size(); i++) g[i] = (!all && i != 0) ? 1 : 0;     // any: [s != 0]; all: 0 below T (and 1 at T)
+    return pbs_box(id, g);
+}
+
+uint32_t Circuit::pbs_box(uint32_t id, const std::vector<uint8_t>& g) {
+    if (id >= nodes_.size()) { set_error("pbs_box: bad node id"); return 0; }
+    const int64_t T = (int64_t)total_modulus();
+    if ((int64_t)g.size() != T) { set_error("pbs_box: the table has msg*carry entries"); return 0; }
+    for (uint8_t v : g) if (v > 1) { set_error("pbs_box: a 0/1 table"); return 0; }
     uint32_t src = id;
     if (nodes_[id].kind != Node::LIN) src = lin({{id, 1}});
     const Node& s = nodes_[src];
-    const int64_t T = (int64_t)total_modulus();
     if (s.vmin < 0 || s.vmax > T) {
-        set_error("pbs_full_box: the sum must lie in [0, msg*carry], got [" + std::to_string(s.vmin) + ", " + std::to_string(s.vmax) + "]");
+        set_error("pbs_box: the input must lie in [0, msg*carry], got [" + std::to_string(s.vmin) + ", " + std::to_string(s.vmax) + "]");
         return 0;
     }
-    if (s.terms.empty()) return trivial(all ? (int64_t)(s.cst == T) : (int64_t)(s.cst != 0));
+    if (s.terms.empty()) return trivial(s.cst == T ? (int64_t)(1 - g[0]) : (int64_t)g[(size_t)s.cst]);
     max_pbs_input_noise_ = std::max(max_pbs_input_noise_, s.noise);
     if (noise_budget_ > 0.0 && s.noise > noise_budget_) {
         char buf[200];
@@ -172,26 +180,29 @@ uint32_t Circuit::pbs_full_box(uint32_t id, bool all) {
         set_error(buf);
         return 0;
     }
-    int& lut_id = full_box_lut_[all ? 1 : 0];
-    if (lut_id < 0) {
+    auto it = box_lut_cache_.find(g);
+    uint32_t lut_id;
+    if (it != box_lut_cache_.end()) {
+        lut_id = it->second;
+    } else {
         const uint64_t half_delta = ((1ull << 63) / (uint64_t)T) / 2;
         std::vector<uint64_t> values((size_t)T), clear((size_t)T);
         for (int64_t i = 0; i < T; i++) {
-            const bool plus = !all && i != 0;
-            values[(size_t)i] = plus ? half_delta : 0 - half_delta;
-            clear[(size_t)i] = plus ? 1 : 0;            // the logical result on [0, T); s = T gives 1 either way
+            values[(size_t)i] = g[(size_t)i] ? half_delta : 0 - half_delta;
+            clear[(size_t)i] = g[(size_t)i];
         }
         std::vector<uint64_t> acc;
         fill_accumulator_torus(p_, values.data(), acc);
-        lut_id = (int)lut_accs_.size();
+        lut_id = (uint32_t)lut_accs_.size();
         lut_accs_.push_back(acc);
         lut_tables_.push_back(clear);                   // not in lut_cache_: an ordinary table with these values is another accumulator
+        box_lut_cache_[g] = lut_id;
     }
     Node n;
     n.kind = Node::PBS;
     n.half = true;
     n.src = src;
-    n.lut = (uint32_t)lut_id;
+    n.lut = lut_id;
     n.level = s.level + 1;
     n.vmin = 0;
     n.vmax = 1;

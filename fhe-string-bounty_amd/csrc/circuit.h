@@ -87,6 +87,9 @@ public:
     // (Node::half: folded into the constant of every linear combination at finalize) -- no extra operation, the same
     // output noise, the same decision margin of delta/2 at the input.  `node` must be a sum with value range [0, T].
     uint32_t pbs_full_box(uint32_t node, bool all);
+    // The general form: any 0/1 table g on [0, T) read on an input in [0, T], where the value at T is forced to 1 - g(0)
+    // by the table's negacyclic extension (so g(0) = 0 for a threshold [x >= theta] whose accept set reaches T).
+    uint32_t pbs_box(uint32_t node, const std::vector<uint8_t>& g);
     // generate_lookup_table with a cache keyed on the table contents (mod.rs:383-399)
     uint32_t lut(const std::vector<uint64_t>& table);
     template <class F>
@@ -177,7 +180,7 @@ private:
     Level out_;
     uint32_t n_inputs_ = 0, n_pbs_ = 0, pool_slots_ = 0, world_ = 1, build_world_ = 1;
     int owner_hint_ = -1;
-    int full_box_lut_[2] = {-1, -1};   // plan-local ids of the two -/+ delta/2 tables ([0] any, [1] all)
+    std::map<std::vector<uint8_t>, uint32_t> box_lut_cache_;   // plan-local ids of the -/+ delta/2 tables, by their 0/1 table
     double noise_budget_ = 0.0, max_pbs_input_noise_ = 0.0;
     std::string error_;
     void* d_meta_ = nullptr;

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <set>
 #include <string>
 
@@ -293,6 +294,72 @@ public:
         }
         return memo[key] = r;
     }
+    // Several pattern characters per lookup (padding_wildcard only; relies on the padding being at the END of the pattern,
+    // z[i] <= z[i+1]).  With a_j in [0, n] the number of equal block (pair)s of character j and z_j its padding bit, the
+    // characters of a group match iff  L = sum_j (c_j a_j + d_j z_j) >= theta = n sum_j c_j  when the weights grow from the
+    // last character backwards as  d_j = n c_j  (a padding character counts as a full match whatever its a_j) and
+    // c_j = 1 + sum_{j' > j} d_j'  (one missing bit of a live character cannot be made up by everything behind it).
+    // L_max = 2 n sum c_j must fit [0, T]: PARAM_MESSAGE_2_CARRY_2 (n = 2 packed pairs per character): two characters,
+    // c = (3, 1), d = (6, 2), L in [0, 16] = the whole box incl. the padding bit (Circuit::pbs_box), 60 nominal variances.
+    // Halves the per-(offset, character) level of contains / find / starts_with.
+    struct GroupWeights { std::vector<int32_t> c, d; int64_t theta = 0, lmax = 0; double noise = 0; };
+    GroupWeights group_weights(uint32_t k, uint32_t n) const {
+        GroupWeights w;
+        w.c.assign(k, 0); w.d.assign(k, 0);
+        int64_t behind = 0, csum = 0;
+        for (int j = (int)k - 1; j >= 0; j--) {
+            w.c[j] = (int32_t)(1 + behind);
+            w.d[j] = (int32_t)(n * w.c[j]);
+            behind += w.d[j];
+            csum += w.c[j];
+            w.noise += (double)w.c[j] * w.c[j] * n + (double)w.d[j] * w.d[j];
+        }
+        w.theta = (int64_t)n * csum;
+        w.lmax = 2 * (int64_t)n * csum;
+        return w;
+    }
+    uint32_t group_size(uint32_t n, uint32_t remaining) const {
+        uint32_t k = 1;
+        while (k < remaining && k < 8) {
+            const GroupWeights w = group_weights(k + 1, n);
+            if (w.lmax > (int64_t)T || w.noise > budget()) break;
+            k++;
+        }
+        return k;
+    }
+    uint32_t group_match(const Str& s, uint32_t ci, const Str& pat, uint32_t pi, uint32_t k, const std::vector<uint32_t>& z,
+                         std::map<std::pair<uint32_t, uint32_t>, std::pair<uint32_t, uint32_t>>& sums,
+                         std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t>& memo) {
+        if (ci >= s.cap) return z[pi];          // the whole group lies behind the string: all of it must be padding = z[pi]
+        auto key = std::make_tuple(ci, pi, k);
+        auto it = memo.find(key);
+        if (it != memo.end()) return it->second;
+        uint32_t n = 0;
+        std::vector<uint32_t> a(k, UINT32_MAX);
+        for (uint32_t j = 0; j < k; j++) {
+            if (ci + j >= s.cap) continue;      // behind the string: no equal blocks, only its padding bit can save it
+            const auto sn = char_eq_sum(s, ci + j, pat, pi + j, sums);
+            a[j] = sn.first;
+            n = sn.second;
+        }
+        const GroupWeights w = group_weights(k, n);
+        std::vector<Term> terms;
+        for (uint32_t j = 0; j < k; j++) {
+            if (a[j] != UINT32_MAX) terms.push_back({a[j], w.c[j]});
+            terms.push_back({z[pi + j], w.d[j]});
+        }
+        const uint32_t L = c.lin(terms);
+        const int64_t theta = w.theta;
+        uint32_t r;
+        if (c.node(L).vmax >= (int64_t)T) {
+            std::vector<uint8_t> g(T);
+            for (uint32_t x = 0; x < T; x++) g[x] = (int64_t)x >= theta;
+            r = c.pbs_box(L, g);
+        } else {
+            r = c.pbs(L, c.lut_fn([theta](uint64_t x) { return (uint64_t)((int64_t)x >= theta); }));
+        }
+        return memo[key] = r;
+    }
     // match[o] for o in [0, n_off): AND_i char_match(s[o+i], pat[i])
     // need_end: additionally require the string to end right after the window (s[o+pat.cap] null)
     std::vector<uint32_t> window_matches(const Str& s, const Str& pat, uint32_t n_off, bool padding_wildcard,
@@ -301,10 +368,21 @@ public:
         std::map<std::pair<uint32_t, uint32_t>, std::pair<uint32_t, uint32_t>> sums;
         std::map<std::pair<uint32_t, uint32_t>, uint32_t> memo;
         std::map<uint32_t, uint32_t> s_zero;
+        std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> group_memo;
+        // characters per lookup: more than one only with wildcard padding, in the default (not reference-shaped) plans
+        uint32_t per_lookup = 1;
+        if (padding_wildcard && full_box_reduce && pat.cap > 1 && s.cap > 0) {
+            // how many equality bits a character has ((s[0], pat[0]) is needed by offset 0 anyway; memoised in `sums`)
+            per_lookup = group_size(char_eq_sum(s, 0, pat, 0, sums).second, pat.cap);
+        }
         std::vector<uint32_t> match;
         for (uint32_t o = 0; o < n_off; o++) {
             Scope sc(c, owner_for(o, n_off));   // a contiguous slice of the offsets per rank
             std::vector<uint32_t> bits;
+            if (per_lookup > 1) {
+                for (uint32_t i = 0; i < pat.cap; i += per_lookup)
+                    bits.push_back(group_match(s, o + i, pat, i, std::min(per_lookup, pat.cap - i), z, sums, group_memo));
+            } else
             for (uint32_t i = 0; i < pat.cap; i++)
                 bits.push_back(char_match(s, o + i, pat, i, z, padding_wildcard, sums, memo));
             if (need_end && o + pat.cap < s.cap) {

@@ -141,9 +141,10 @@ def test_plan_shapes_match_survey_counts():
     assert _plan("eq", 256, 256).info()["n_pbs"] == 512 + 32 + 2 + 1
     info = _plan("eq_clear", 256, 0, b"x" * 200).info()
     assert (info["n_pbs"], info["n_levels"]) == (547, 4)
-    # contains, 16-char encrypted pattern in 256 chars: AND over the 16 chars and OR over the 241 offsets lose a level each
+    # contains, 16-char encrypted pattern in 256 chars: AND over the 16 chars and OR over the 256 offsets lose a level each,
+    # and two pattern characters share one lookup of the (offset, character) level (fhe_string.cpp: group_match)
     plan = _plan("contains", 256, 16)
-    assert [plan.level_info(l)["jobs"] for l in range(plan.info()["n_levels"])] == [7968, 3976, 256, 16, 1]
+    assert [plan.level_info(l)["jobs"] for l in range(plan.info()["n_levels"])] == [7968, 1992, 256, 16, 1]
     plan = _plan("contains_reference", 256, 16)
     assert [plan.level_info(l)["jobs"] for l in range(plan.info()["n_levels"])] == [15920, 3991, 497, 256, 18, 2, 1]
     lv = [_plan("eq_reference", 256, 256).level_info(l)["jobs"] for l in range(4)]
@@ -560,3 +561,29 @@ def test_find_contains_over_more_than_16_offsets(toy_k1, s, pat):
             digits = out[1:]
             got = sum(d * P.msg_mod**i for i, d in enumerate(digits))
             assert out[0] == int(idx >= 0) and (idx < 0 or got == idx), (op, out, idx)
+
+
+@pytest.mark.parametrize("pat_len", [0, 1, 2, 3, 4, 5])
+def test_two_pattern_characters_per_lookup_every_padding_position(toy_k1, pat_len):
+    """group_match (fhe_string.cpp): pairs of pattern characters share one lookup, weighted so that padding counts as a
+    match and one wrong block of a live character cannot be made up.  Pattern capacity 5 (two pairs + a single), every
+    length 0 .. 5 (the padding starts inside a pair, between pairs, nowhere), haystacks that match, that differ in the
+    first / second character of a pair only, in one block only, and windows that run past the end of the haystack."""
+    import fhestr
+    P = to_fhestr_params(O.TOY_K1)
+    pat = b"abcde"[:pat_len]
+    hays = [b"xxabcdex", b"abcdexxx", b"xxxabcde", b"xxabcdfx", b"xxaccdex", b"xxbbcdex", b"xxabcd", b"abcd", b"", b"xxabqdex",
+            b"xxabcdeq"[:8], b"xabcdabc"]
+    for op in ("contains", "starts_with", "find"):
+        plan = fhestr.Plan.string_op(None, op, 8, 5, None, 1, params=P)
+        for hay in hays:
+            inputs = np.concatenate([_enc(toy_k1, hay, 8), _enc(toy_k1, pat, 5)])
+            out = toy_k1.ck.decrypt_many(run_with_oracle(plan, inputs, toy_k1.sk)).tolist()
+            if op == "contains":
+                assert out == [int(pat in hay)], (op, hay, pat, out)
+            elif op == "starts_with":
+                assert out == [int(hay.startswith(pat))], (op, hay, pat, out)
+            else:
+                idx = hay.find(pat)
+                got = sum(d * P.msg_mod**i for i, d in enumerate(out[1:]))
+                assert out[0] == int(idx >= 0) and (idx < 0 or got == idx), (op, hay, pat, out)
