@@ -382,6 +382,28 @@ public:
             if (per_lookup > 1) {
                 for (uint32_t i = 0; i < pat.cap; i += per_lookup)
                     bits.push_back(group_match(s, o + i, pat, i, std::min(per_lookup, pat.cap - i), z, sums, group_memo));
+            } else if (!padding_wildcard && full_box_reduce) {
+                // exact match incl. padding: no per-character lookup at all -- the equal-block counts of up to T / n
+                // characters are summed and tested against their maximum in one lookup (T itself through pbs_full_box)
+                std::vector<Term> run;
+                int64_t run_max = 0;
+                auto flush = [&]() {
+                    if (run.empty()) return;
+                    const uint32_t sum = c.lin(run);
+                    const int64_t want = run_max;
+                    bits.push_back(want == (int64_t)T ? c.pbs_full_box(sum, true)
+                                                      : c.pbs(sum, c.lut_fn([want](uint64_t x) { return (uint64_t)((int64_t)x == want); })));
+                    run.clear();
+                    run_max = 0;
+                };
+                for (uint32_t i = 0; i < pat.cap; i++) {
+                    if (o + i >= s.cap) { bits.push_back(z[i]); continue; }       // behind the string: the pattern must be padding there
+                    const auto sn = char_eq_sum(s, o + i, pat, i, sums);
+                    if (run_max + (int64_t)sn.second > (int64_t)T || c.node(sn.first).noise * (double)(run.size() + 1) > budget()) flush();
+                    run.push_back({sn.first, 1});
+                    run_max += sn.second;
+                }
+                flush();
             } else
             for (uint32_t i = 0; i < pat.cap; i++)
                 bits.push_back(char_match(s, o + i, pat, i, z, padding_wildcard, sums, memo));
