@@ -267,7 +267,8 @@ int fhe_int_plan_create_offline(const fhe_params_t *params, const char *op, uint
 /* ---- FheString operations --------------------------------------------------------------------- */
 /* An encrypted string = `cap` characters, zero padded, each character 8/log2(msg_mod) big-key LWE
  * blocks, little endian (integer/block_decomposition.rs:119-144): cap * blocks * (kN+1) u64.
- * Results decrypt to what the clear-text function gives on the unpadded ASCII strings.
+ * Results decrypt to what the clear-text function gives on the unpadded ASCII strings.  The zero characters come
+ * after the text and nowhere else (the searches with an encrypted pattern rely on it: csrc/fhe_string.cpp, group_match).
  * op in {"eq","ne","starts_with","ends_with","contains","find"} (+ "_clear" suffix for a clear
  * pattern) or {"to_upper","to_lower","trim_start","trim_end","strip","replace","replace_clear","concat",
  * "concat_clear","repeat_clear"}.  Outputs: one 0/1 block; find: found block then
