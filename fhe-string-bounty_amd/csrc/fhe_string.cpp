@@ -864,6 +864,15 @@ public:
         };
         oc.sel.resize(match.size());
         const uint32_t l3 = c.lut_fn([](uint64_t x) { return (uint64_t)(x == 3); });
+        // Two offsets per lookup level (default plans).  sel[o+1] needs sel[o], but sel[o] = match[o] AND NOT B with
+        // B = [an earlier occurrence still runs at o], so with p = match[o] AND [the pattern is longer than one character]
+        // (off the chain) and B' = [an earlier occurrence still runs at o + 1] (B' <= B: the same occurrence, one character on):
+        //   sel[o+1] = match[o+1] AND NOT (p AND NOT B) AND NOT B',   one lookup on  (B + B') + 3 p + 6 match[o+1]  in [0, 11]
+        // at the same level as sel[o].  Halves the depth of the recurrence (one level per TWO offsets).
+        const uint32_t l_second = c.lut_fn([](uint64_t x) {
+            const uint64_t mt = x / 6, pp = (x % 6) / 3, t = x % 3;
+            return (uint64_t)(mt == 1 && !(pp == 1 && t == 0) && t != 2);
+        });
         for (uint32_t o = 0; o < match.size(); o++) {
             std::vector<uint32_t> blockers;
             if (may_overlap)
@@ -872,10 +881,28 @@ public:
             // x = 2 match + 1 - (blockers; at most one is set) in {0..3}; selected iff x == 3
             double nu = 4 * c.node(match[o]).noise;
             for (uint32_t b : blockers) nu += c.node(b).noise;
-            if (nu > budget()) blockers.assign(1, reduce_local(blockers, false));
+            const bool reduced = nu > budget();
+            if (reduced) blockers.assign(1, reduce_local(blockers, false));
             std::vector<Term> terms{{match[o], 2}};
             for (uint32_t b : blockers) terms.push_back({b, -1});
             oc.sel[o] = c.pbs(c.lin(terms, 1, 3), l3);
+            if (!full_box_reduce || reduced || o + 1 >= match.size() || T < 12) continue;
+            // the second offset of the pair, from what was known before sel[o]
+            std::vector<Term> tt;
+            double nu2 = 36 * c.node(match[o + 1]).noise;
+            for (uint32_t b : blockers) { tt.push_back({b, 1}); nu2 += c.node(b).noise; }
+            for (uint32_t j = 2; j < m && j <= o + 1; j++) {
+                const uint32_t b = run_bit(o + 1 - j, j);
+                tt.push_back({b, 1});
+                nu2 += c.node(b).noise;
+            }
+            const uint32_t p_bit = nzf ? and_bits(match[o], (*nzf)[1]) : match[o];
+            nu2 += 9 * c.node(p_bit).noise;
+            if (nu2 > budget()) continue;
+            tt.push_back({p_bit, 3});
+            tt.push_back({match[o + 1], 6});
+            oc.sel[o + 1] = c.pbs(c.lin(tt, 0, 11), l_second);
+            o++;
         }
         oc.cover.resize(n_chars);
         for (uint32_t i = 0; i < n_chars; i++) {

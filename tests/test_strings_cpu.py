@@ -587,3 +587,25 @@ def test_two_pattern_characters_per_lookup_every_padding_position(toy_k1, pat_le
                 idx = hay.find(pat)
                 got = sum(d * P.msg_mod**i for i, d in enumerate(out[1:]))
                 assert out[0] == int(idx >= 0) and (idx < 0 or got == idx), (op, hay, pat, out)
+
+
+@pytest.mark.parametrize("s,frm", [(b"aaaaaaa", b"aa"), (b"aaaaaa", b"aaa"), (b"abaabaab", b"aba"), (b"aaaaaaaa", b"a"), (b"ababababa", b"ab"),
+                                   (b"aabaabaa", b"aab"), (b"xaaaaaax", b"aaa"), (b"aaaaaaaa", b"aaa")])
+def test_replace_occurrence_recurrence_two_offsets_per_level(toy_k1, s, frm):
+    """occurrences() (fhe_string.cpp) settles two offsets per lookup level: self-overlapping patterns of every true
+    length inside a capacity-3 padded encrypted pattern (the blocking of the next offset depends on whether the pattern is
+    longer than one character), leftmost non-overlapping selection as bytes.replace does it.  Oracle-executed."""
+    import fhestr
+    P = to_fhestr_params(O.TOY_K1)
+    to = b"XYZ"[:len(frm)]
+    want = s.replace(frm, to)
+    cap = 9
+    # equal-length in-place form, unpadded encrypted operands
+    plan = _plan("replace", cap, 2 * len(frm))
+    inputs = np.concatenate([_enc(toy_k1, s, cap), _enc(toy_k1, frm, len(frm)), _enc(toy_k1, to, len(to))])
+    assert fhestr.blocks_to_string(P, toy_k1.ck.decrypt_many(run_with_oracle(plan, inputs, toy_k1.sk))) == want
+    assert plan.info()["n_levels"] < cap + 6            # one level per two offsets, not per offset
+    # general form, zero padded encrypted operands of capacity 3 (hidden length)
+    plan = _plan(f"replace:3:{cap}", cap, 6)
+    inputs = np.concatenate([_enc(toy_k1, s, cap), _enc(toy_k1, frm, 3), _enc(toy_k1, to, 3)])
+    assert fhestr.blocks_to_string(P, toy_k1.ck.decrypt_many(run_with_oracle(plan, inputs, toy_k1.sk))) == want
