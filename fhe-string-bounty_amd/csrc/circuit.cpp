@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "noise_model.h"
@@ -136,7 +137,13 @@ uint32_t Circuit::pbs(uint32_t id, uint32_t lut_id, bool signed_input) {
         char buf[200];
         snprintf(buf, sizeof buf, "pbs: input noise %.1f nominal variances exceeds this parameter set's budget of %.1f",
                  s.noise, noise_budget_);
-        set_error(buf);
+        std::string detail = buf;
+        if (getenv("FHESTR_DEBUG_NOISE")) {
+            detail += " [terms:";
+            for (const Term& t : s.terms) detail += " " + std::to_string(t.coeff) + "*n" + std::to_string(nodes_[t.node].noise);
+            detail += "]";
+        }
+        set_error(detail);
         return 0;
     }
     Node n;

@@ -14,6 +14,7 @@
 // blocks, little endian (integer/block_decomposition.rs:119-144).  Semantics of every operation =
 // the corresponding clear-text function on the unpadded ASCII string.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <tuple>
@@ -727,6 +728,20 @@ public:
         return c.pbs(c.lin({{bit, 1}, {block, 2}}), l);
     }
     uint32_t not_bit(uint32_t bit) { return c.lin({{bit, -1}}, 1, 1); }
+    // sel ? b : a for two blocks in [0, M-1] in ONE lookup (default plans): a + sel * (b - a), the product read off
+    // (b - a) + (M-1) + (2M-1) sel in [0, 4M-3].  The result keeps a's noise plus one nominal variance (the two-gate form
+    // returns two fresh lookups): callers that chain it clean the blocks at the end (fresh()).  Falls back to the two
+    // gates where the packing does not fit the box or the budget (PARAM_MESSAGE_4_CARRY_4: (2M-1)^2 = 961 variances).
+    uint32_t select_block(uint32_t a, uint32_t b, uint32_t sel, uint32_t hi) {
+        int64_t v = 0;
+        if (is_trivial(sel, &v)) return v ? b : a;
+        const uint32_t D = 2 * hi + 1;                           // distinct values of b - a, both in [0, hi]
+        const uint32_t x = full_box_reduce && 2 * D <= T ? c.lin({{b, 1}, {a, -1}, {sel, (int32_t)D}}, (int64_t)hi) : UINT32_MAX;
+        if (x == UINT32_MAX || c.node(x).noise > budget())       // (noise of the combination as built: shared sources add up)
+            return c.lin({{gate_block(a, sel, false), 1}, {gate_block(b, sel, true), 1}}, 0, hi);
+        const uint32_t l = c.lut_fn([D, hi](uint64_t y) { return (uint64_t)(y >= 2 * D ? hi : (y / D ? y % D : hi)); });
+        return c.lin({{a, 1}, {c.pbs(x, l), 1}}, -(int64_t)hi, (int64_t)hi);
+    }
     // trim_end: zero every char from the last non-whitespace one onwards
     Str trim_end(const Str& s) {
         std::vector<uint32_t> wz = whitespace_bits(s, true), nw(s.cap);
@@ -768,17 +783,30 @@ public:
             std::vector<uint32_t> nlead(s.cap);
             for (uint32_t i = 0; i < s.cap; i++) {
                 for (size_t k = 0; k < cur.ch[i].size(); k++) {
-                    const uint32_t stay = gate_block(cur.ch[i][k], sel, false);
-                    if (i + sh < s.cap) nxt.ch[i].push_back(c.lin({{stay, 1}, {gate_block(cur.ch[i + sh][k], sel, true), 1}}, 0, M - 1));
-                    else nxt.ch[i].push_back(stay);
+                    if (i + sh < s.cap) nxt.ch[i].push_back(select_block(cur.ch[i][k], cur.ch[i + sh][k], sel, M - 1));
+                    else nxt.ch[i].push_back(gate_block(cur.ch[i][k], sel, false));
                 }
                 // the monotone indicator shifts with the string
-                const uint32_t stay = gate_block(lead[i], sel, false);
-                nlead[i] = i + sh < s.cap ? c.lin({{stay, 1}, {gate_block(lead[i + sh], sel, true), 1}}, 0, 1) : stay;
+                // (a fresh bit every stage -- it is the next stages' selector, whose noise is weighted (2M-1)^2 above:
+                //  one lookup on lead[i] + 2 lead[i + sh] + 4 sel)
+                // (the noise of the combination as built: operands that share sources, e.g. lead[i] == sel, add up)
+                const uint32_t packed3 = i + sh < s.cap && full_box_reduce && T >= 8
+                                             ? c.lin({{lead[i], 1}, {lead[i + sh], 2}, {sel, 4}}) : UINT32_MAX;
+                if (packed3 != UINT32_MAX && c.node(packed3).noise <= budget()) {
+                    int64_t va = 0, vb = 0;
+                    const bool ta = is_trivial(lead[i], &va), tb = is_trivial(lead[i + sh], &vb);
+                    if (ta && tb && va == vb) nlead[i] = lead[i];
+                    else nlead[i] = c.pbs(packed3, c.lut_fn([](uint64_t x) { return (uint64_t)((x & 4) ? (x >> 1) & 1 : x & 1); }));
+                } else
+                nlead[i] = i + sh < s.cap ? select_block(lead[i], lead[i + sh], sel, 1) : c.lin({{gate_block(lead[i], sel, false), 1}}, 0, 1);
             }
             cur = nxt;
             lead = nlead;
         }
+        // blocks that went through select_block stages carry one nominal variance per stage: back to a fresh lookup's
+        for (auto& chr : cur.ch)
+            for (uint32_t& b : chr)
+                if (c.node(b).noise > 2.0) b = fresh(b);
         return cur;
     }
     // Concatenation of two left-justified strings whose per-slot occupancy bits are known (occ): the
