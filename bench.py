@@ -11,6 +11,8 @@ LWEs of all ranks / max-over-ranks time.
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...      (no launcher: bench.py starts that torch.distributed.run itself, as a fresh child
+                                       process before anything touches the GPU, relays rank 0's line and its exit code)
 """
 import argparse
 import json
@@ -33,7 +35,7 @@ COUNTERS_P44 = os.path.join(ROOT, "profiles", "r03_p44_counters.json")   # the s
 SEED = 0x5EED0002
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -45,7 +47,39 @@ def parse():
     ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep")
     ap.add_argument("--no-p44", action="store_true", help="skip the PARAM_MESSAGE_4_CARRY_4 (config 5) section")
     ap.add_argument("--serial", action="store_true", help="headline without the keyswitch / blind-rotation pipelining")
-    return ap.parse_args()
+    ap.add_argument("--print-launch", action="store_true", help="print the torch.distributed.run command --gpus N > 1 would start, and exit")
+    return ap.parse_args(argv)
+
+
+def launch_command(argv, gpus, port, script=None):
+    """The command `bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) starts: one rank per GPU under
+    torch.distributed.run on this node, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    rest = [a for a in argv if a != "--print-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script or os.path.abspath(__file__)] + rest
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(argv, gpus, script=None):
+    """`python bench.py --gpus N` without a launcher: start the ranks as a FRESH child process tree (this process has
+    touched neither torch.cuda nor libfhestr, and never will), relay what they print, return the launcher's exit code.
+    A rank that fails makes torch.distributed.run exit non-zero, and that is what the driver sees."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = launch_command(argv, gpus, free_port(), script)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in child.stdout:          # rank 0's JSON line (and nothing else) arrives on stdout
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
 
 
 def cpu_baseline(P, bsk, ksk, cts, lut_tables, lut_sel):
@@ -475,9 +509,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.print_launch:
+        print(json.dumps(launch_command(sys.argv[1:], args.gpus, 0)))
+        return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as `python bench.py --gpus N`: become the launcher (before anything touches the GPU)
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
     import torch
@@ -752,6 +790,10 @@ def main():
             except Exception as e:  # the baseline is informative; never let it kill the GPU number
                 rec["cpu_baseline"] = {"value": None, "unit": "PBS/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
+        else:
+            rec["cpu_baseline"] = None
+            rec["cpu_baseline_reason"] = ("--no-cpu-baseline" if args.no_cpu_baseline else
+                                          "timed on rank 0 at N = 1 only (the contract); see the N = 1 line of the same tree")
         print(json.dumps(rec), flush=True)
     if world > 1:
         # the headline line is out; never let the teardown of a wedged collective keep the job alive
