@@ -142,7 +142,7 @@ int fhe_engine_set_multibit_combine_max(fhe_engine* eng, uint32_t max_batch) {
 int fhe_engine_set_cluster_mode(fhe_engine* eng, int mode, uint32_t max_batch) {
     API_BEGIN
     CHECK_PTR(eng); LOCK_ENGINE(eng);
-    if (mode < -1 || mode > 1) return fhe::fail("cluster mode: -1 (automatic), 0 (never) or 1 (always)");
+    if (mode < -1 || mode > 2) return fhe::fail("cluster mode: -1 (automatic), 0 (never), 1 (always) or 2 (always, the 8-CU clusters of round 3)");
     eng->impl->cluster_mode = mode;
     eng->impl->cluster_max_batch = max_batch;
     return 0;
@@ -573,6 +573,13 @@ int fhe_host_free(void* ptr) {
     API_BEGIN
     if (ptr && hipHostFree(ptr) != hipSuccess) return fhe::fail("fhe_host_free: not a buffer of fhe_host_alloc");
     return 0;
+    API_END
+}
+
+int fhe_params_supported(const fhe_params_t* params) {
+    API_BEGIN
+    CHECK_PTR(params);
+    return fhe::params_supported(*params);
     API_END
 }
 

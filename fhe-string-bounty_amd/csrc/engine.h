@@ -67,9 +67,10 @@ struct Engine {
     bool keep_busy = false;                  // small launches carry replicas on the idle CUs (fhe_engine_set_keep_busy, FHESTR_KEEP_BUSY)
     hipStream_t ovl_stream[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ovl_done[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};
-    const void* ovl_in[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};
-    const void* ovl_out[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};
-    size_t ovl_bytes[OVL_MAX] = {0, 0, 0, 0};
+    // byte ranges every call of the current run read / wrote, per stream (a later call on ANOTHER stream that touches one of
+    // them waits for that stream's latest ovl_done: stream order then covers all of its earlier calls -- ADVICE r3)
+    struct ByteRange { const char* lo; const char* hi; };
+    std::vector<ByteRange> ovl_ins[OVL_MAX], ovl_outs[OVL_MAX];
     uint64_t* ovl_small[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};      // small-ciphertext buffer per stream
     size_t ovl_cap_small[OVL_MAX] = {0, 0, 0, 0};
     int8_t* ovl_digits[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};       // keyswitch digit fragments per stream (slot 0: d_ks_digits)
@@ -81,7 +82,6 @@ struct Engine {
     uint32_t multibit_combine_max = 64;       // multi-bit PBS: batches up to this size prepare their GGSWs on the whole GPU first
 
     // resident keys / tables
-    uint64_t* d_ksk = nullptr;       // reference layout (kept only when the byte-plane path is disabled)
     uint32_t* d_ksk_packed = nullptr; // [rows/4][8][n+1] byte planes for keyswitch_dot4_kernel
     uint64_t* d_ksk_rowsum = nullptr; // [kN / KS_IC][n+1] sums of every tile's key rows (bias removal)
     int8_t* d_ksk_mfma = nullptr;     // balanced base-256 digit planes of the KSK in MFMA B-fragment order (ks_mfma_kernels.hip.h)
@@ -108,6 +108,7 @@ struct Engine {
     uint32_t cluster_last = 0;      // clusters the last checked launch formed
     int cluster_mode = -1;          // -1 automatic (by batch size), 0 never, 1 always (FHESTR_CLUSTER)
     uint32_t cluster_max_batch = 0xFFFFFFFFu;
+    uint32_t xcd_auto_max = 16;     // automatic mode: batches up to this size take the whole-XCD kernel (two LWEs per XCD in flight)
     uint32_t cluster_spin_limit = 1u << 22;   // polls before a hand-over wait gives up (FHESTR_CLUSTER_SPIN_LIMIT)
     uint32_t cluster_test_fault = 0;          // tests only (FHESTR_CLUSTER_TEST_FAULT): epoch one workgroup stays silent at
     int cluster_check();            // after a synchronisation: did a cluster launch give up on a hand-over?
@@ -150,6 +151,8 @@ struct Engine {
     int kernel_times(double total_ms[2], uint32_t* calls, bool reset);
     int synchronize();
 };
+
+int params_supported(const fhe_params_t& p);   // 0, or 1 with the reason in fhe_last_error (no device needed)
 
 }  // namespace fhe
 

@@ -5,7 +5,7 @@
 // (shortint/server_key/mod.rs:783-857, shortint/engine/mod.rs:184-234).  Here the keys are made
 // resident in HBM once (BSK 48.6 MB + KSK 60.9 MB for PARAM_MESSAGE_2_CARRY_2: both sit in the
 // 256 MB Infinity Cache) and whole batches of LWEs go through three launches on one HIP stream:
-// memset -> keyswitch_kernel -> blind_rotate_kernel.
+// memset -> keyswitch (ks_decompose + keyswitch_mfma_kernel) -> blind rotation.
 #include "engine.h"
 
 #include <algorithm>
@@ -21,6 +21,7 @@
 #include "pbs_kernels.hip.h"
 #include "pbs_large_kernels.hip.h"
 #include "pbs_cluster_kernels.hip.h"
+#include "pbs_xcd_kernels.hip.h"
 #include "pbs_multibit_kernels.hip.h"
 #include "pbs_seq_kernels.hip.h"
 #include "seeded_kernels.hip.h"
@@ -71,6 +72,10 @@ struct BrVariant {
     int cluster_size = 0;         // workgroups per LWE
     size_t cluster_ws = 0;        // workspace bytes per cluster
     size_t cluster_lds = 0;
+    // N = 32768, two levels: all CUs of an XCD per LWE, two LWEs in flight per XCD (pbs_xcd_kernels.hip.h)
+    const void* xcd_fn = nullptr;
+    int xcd_size = 0, xcd_threads = 0;
+    size_t xcd_ws = 0, xcd_lds = 0, xcd_lds_one_per_cu = 0;
 };
 
 template <int LOGN, int LOGR, int K1, int L>
@@ -119,6 +124,15 @@ BrVariant make_large_variant() {
         v.cluster_size = CC::C;
         v.cluster_ws = CC::WS_BYTES;
         v.cluster_lds = CC::LDS_BYTES;
+        if constexpr (L == 2 && LOGN == 15) {
+            using XC = BrXcdCfg<LOGN, K1, L>;
+            v.xcd_fn = reinterpret_cast<const void*>(&blind_rotate_xcd_kernel<LOGN, K1, L>);
+            v.xcd_size = XC::C;
+            v.xcd_threads = XC::THREADS;
+            v.xcd_ws = XC::WS_BYTES;
+            v.xcd_lds = XC::LDS_BYTES;
+            v.xcd_lds_one_per_cu = XC::LDS_TWO_PER_CU + 1024;     // more than half of a CU's LDS: one workgroup per CU
+        }
     }
     return v;
 }
@@ -248,19 +262,29 @@ static const BrVariant* find_variant(const fhe_params_t& p, int selector) {
 }
 
 // ---- Engine -----------------------------------------------------------------------------------
-int Engine::create(const fhe_params_t& p, int device, Engine** out) {
+// Everything Engine::create checks before it touches a device: shapes the kernels are instantiated for, decomposition
+// ranges of the keyswitch paths (any level count: more than 16 levels take the byte-plane kernel, ks_mfma_supported).
+int params_supported(const fhe_params_t& p, int selector, const BrVariant** out_v) {
     if ((p.N & (p.N - 1)) || p.N < 128) return fail("polynomial size must be a power of two >= 128");
     if (p.pbs_base_log < 1 || p.pbs_base_log > 31 || p.pbs_base_log * p.pbs_level > (p.pbs_level >= 3 ? 62u : 31u))
         return fail("unsupported PBS decomposition (base_log * level must be <= 31, or <= 62 with >= 3 levels)");
-    if (p.ks_base_log < 1 || p.ks_base_log > 7 || p.ks_base_log * p.ks_level > 62)
-        return fail("unsupported keyswitch decomposition");
+    if (p.ks_level < 1 || p.ks_base_log < 1 || p.ks_base_log > 7 || p.ks_base_log * p.ks_level > 62)
+        return fail("unsupported keyswitch decomposition (base_log 1..7, base_log * level <= 62)");
     if (p.msg_mod * p.carry_mod == 0 || (p.N % (p.msg_mod * p.carry_mod)) != 0)
         return fail("msg_mod * carry_mod must divide N");
-    int env_logr = 0;
-    if (const char* e = getenv("FHESTR_LOG2_POINTS")) env_logr = atoi(e);
-    const BrVariant* v = find_variant(p, env_logr);
+    const BrVariant* v = find_variant(p, selector);
     if (p.grouping_factor > 1 && (p.n % p.grouping_factor) != 0) return fail("grouping factor must divide n");
     if (!v) return fail("no blind-rotation kernel instantiated for this (N, k, level, grouping factor)");
+    if (out_v) *out_v = v;
+    return 0;
+}
+int params_supported(const fhe_params_t& p) { return params_supported(p, 0, nullptr); }
+
+int Engine::create(const fhe_params_t& p, int device, Engine** out) {
+    int env_logr = 0;
+    if (const char* e = getenv("FHESTR_LOG2_POINTS")) env_logr = atoi(e);
+    const BrVariant* v = nullptr;
+    if (params_supported(p, env_logr, &v)) return 1;
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     if (count <= 0) return fail("no HIP device: libfhestr has no CPU fallback");
@@ -276,8 +300,10 @@ int Engine::create(const fhe_params_t& p, int device, Engine** out) {
     if (const char* m = getenv("FHESTR_OVERLAP_STREAMS")) e->ovl_streams = std::min((int)Engine::OVL_MAX, std::max(2, atoi(m)));
     if (const char* m = getenv("FHESTR_KS_MFMA")) e->ks_mfma_enabled = atoi(m) != 0;
     if (const char* m = getenv("FHESTR_CLUSTER_SPIN_LIMIT")) e->cluster_spin_limit = (uint32_t)std::max(64, atoi(m));
-    if (const char* m = getenv("FHESTR_CLUSTER_TEST_FAULT")) e->cluster_test_fault = (uint32_t)std::max(0, atoi(m));   // tests only
-    if (const char* m = getenv("FHESTR_CLUSTER")) e->cluster_mode = std::min(1, std::max(-1, atoi(m)));
+#ifdef FHESTR_TEST_HOOKS      // fault injection exists only in the test build (make testhooks), never in the product library
+    if (const char* m = getenv("FHESTR_CLUSTER_TEST_FAULT")) e->cluster_test_fault = (uint32_t)std::max(0, atoi(m));
+#endif
+    if (const char* m = getenv("FHESTR_CLUSTER")) e->cluster_mode = std::min(2, std::max(-1, atoi(m)));
     if (const char* m = getenv("FHESTR_MULTIBIT_COMBINE_MAX")) e->multibit_combine_max = (uint32_t)std::min(1024, std::max(0, atoi(m)));
     if (env_logr == 0) {   // automatic: "wide" twin (same points per thread => same key layout) for big batches
         const BrVariant* w = find_variant(p, v->logR | 16);
@@ -295,9 +321,9 @@ int Engine::create(const fhe_params_t& p, int device, Engine** out) {
 
 Engine::~Engine() {
     (void)hipSetDevice(device);
-    if (stream) (void)hipStreamSynchronize(stream);
+    if (stream) (void)sync_all_streams();
     auto rel = [](void* ptr) { if (ptr) (void)hipFree(ptr); };
-    rel(d_ksk); rel(d_ksk_packed); rel(d_ksk_rowsum); rel(d_fbsk); rel(d_luts); rel(d_in); rel(d_small); rel(d_small2); rel(d_out); rel(d_idx);
+    rel(d_ksk_packed); rel(d_ksk_rowsum); rel(d_fbsk); rel(d_luts); rel(d_in); rel(d_small); rel(d_small2); rel(d_out); rel(d_idx);
     rel(d_pool); rel(d_meta); rel(d_ws); rel(d_slot_exp); rel(d_cluster_ws); rel(d_cluster_ctl); rel(d_ksk_mfma); rel(d_ks_digits);
     for (int q = 0; q < OVL_MAX; q++) { rel(ovl_digits[q]); rel(ovl_small[q]); if (ovl_done[q]) (void)hipEventDestroy(ovl_done[q]); if (q >= 2 && ovl_stream[q]) (void)hipStreamDestroy(ovl_stream[q]); }
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -554,11 +580,9 @@ int Engine::install_keys(uint64_t* d_ksk_std, uint64_t* d_std) {
         ~Guard() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); }
     } guard{d_ksk_std, d_std};
     const size_t bsk_len = (size_t)n_ggsw(p) * p.pbs_level * (p.k + 1) * (p.k + 1) * p.N;
-    if (d_ksk) { HIP_TRY(hipFree(d_ksk)); d_ksk = nullptr; }
     if (d_fbsk) { HIP_TRY(hipFree(d_fbsk)); d_fbsk = nullptr; }
     if (d_ksk_packed) { HIP_TRY(hipFree(d_ksk_packed)); d_ksk_packed = nullptr; }
-    static const bool use_dot4 = !(getenv("FHESTR_KS_MAD64") && atoi(getenv("FHESTR_KS_MAD64")));
-    if (use_dot4) {   // repack into byte planes once; the 64-bit layout is then released
+    {   // repack into byte planes once; the 64-bit layout is then released
         const uint32_t rows = p.k * p.N * p.ks_level, osz = p.n + 1;
         HIP_TRY(hipMalloc((void**)&d_ksk_packed, (size_t)(rows / 4) * 8 * osz * 4));
         hipLaunchKernelGGL(ksk_pack_kernel, dim3((osz + 255) / 256, rows / 4), dim3(256), 0, stream,
@@ -570,12 +594,12 @@ int Engine::install_keys(uint64_t* d_ksk_std, uint64_t* d_std) {
                            d_ksk_std, d_ksk_rowsum, rows, osz, (uint32_t)KS_IC * p.ks_level);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
-    } else {
-        d_ksk = d_ksk_std;
-        d_ksk_std = nullptr;          // kept: the mad64 kernel reads the 64-bit layout
     }
     if (d_ksk_mfma) { HIP_TRY(hipFree(d_ksk_mfma)); d_ksk_mfma = nullptr; }
-    if (use_dot4 && ks_mfma_enabled) {   // balanced base-256 digit planes in MFMA fragment order (ks_mfma_kernels.hip.h)
+    // balanced base-256 digit planes in MFMA fragment order (ks_mfma_kernels.hip.h); a 16-slot group holds whole mask
+    // elements with all their levels, so more than 16 levels (PARAM_MESSAGE_3_CARRY_4_COMPACT_PK_PBS_KS: 22) stay on the
+    // byte-plane dot4 kernel
+    if (ks_mfma_enabled && ks_mfma_supported(p.ks_level)) {
         const KsMfmaGeom g = ks_mfma_geom(p.k * p.N, p.n + 1, p.ks_level, p.ks_base_log);
         const size_t bytes = (size_t)g.col_groups * g.steps * 8 * 1024;
         HIP_TRY(hipMalloc((void**)&d_ksk_mfma, bytes));
@@ -664,7 +688,7 @@ int Engine::ensure_batch(uint32_t count) {
 }
 
 int Engine::launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t count, hipStream_t on, bool shadow, int digits_slot) {
-    if (!d_ksk && !d_ksk_packed) return fail("keys not loaded");
+    if (!d_ksk_packed) return fail("keys not loaded");
     hipStream_t s = on ? on : stream;
     // grid.y = sample tiles; HIP caps grid.y at 65535
     if (count > 65535u * KSD_S) return fail("batch too large for one keyswitch launch (max 524280 LWEs)");
@@ -695,6 +719,7 @@ int Engine::launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t cou
         uint32_t chunks = (6u * (uint32_t)cu_count + g.col_groups * gy * mt / 2) / (g.col_groups * gy * mt);
         if (const char* e = getenv("FHESTR_KS_CHUNKS")) chunks = (uint32_t)atoi(e);
         chunks = std::max(1u, std::min(chunks, (g.steps + 7) / 8));
+        chunks = std::max(chunks, (g.steps + ks_mfma_max_steps(p.ks_base_log) - 1) / ks_mfma_max_steps(p.ks_base_log));   // int32 accumulators
         const uint32_t spc = (g.steps + chunks - 1) / chunks;
         chunks = (g.steps + spc - 1) / spc;
         KsMfmaArgs ma{d_big, d_ksk_mfma, digits, d_sm, g, count, row_tiles, spc};
@@ -722,12 +747,7 @@ int Engine::launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t cou
         HIP_TRY(hipGetLastError());
         return 0;
     }
-    KeyswitchArgs a{d_big, d_ksk, d_sm, in_dim, out_size, p.ks_base_log, p.ks_level, count};
-    dim3 grid((out_size + KS_COLS - 1) / KS_COLS, (count + KS_S - 1) / KS_S, (in_dim + KS_IC - 1) / KS_IC);
-    const size_t lds = (size_t)KS_IC * p.ks_level * KS_S;
-    hipLaunchKernelGGL(keyswitch_kernel, grid, dim3(KS_COLS), lds, s, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return fail("keyswitch key not installed");
 }
 
 int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx, uint64_t* d_big,
@@ -809,7 +829,38 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
     }
     // (a device with fewer than 8 * C compute units -- e.g. one XCD of a partitioned GPU -- cannot host a grid of the
     // cluster kernel: it takes the one-workgroup kernel below)
-    if (v->cluster_fn && cluster_mode != 0 && (cluster_mode == 1 || count <= cluster_max_batch) &&
+    // automatic mode: the whole-XCD kernel up to two LWEs per XCD (one LWE 12.3 ms, 16 LWEs 18.4 ms; the 8-CU clusters: 20.9 /
+    // 21.4 ms), the 8-CU clusters above (256 LWEs: 1.15 k PBS/s against 0.85 k -- four LWEs in flight per XCD amortise the
+    // hand-over latency better than two; profiles/r04_xcd_history.txt)
+    if (v->xcd_fn && cluster_mode != 0 && cluster_mode != 2 && (cluster_mode == 1 || count <= std::min(cluster_max_batch, xcd_auto_max)) &&
+        (uint32_t)cu_count >= 8u * (uint32_t)v->xcd_size) {
+        // All CUs of an XCD per LWE (pbs_xcd_kernels.hip.h).  Up to 8 LWEs: one cluster per XCD, one 256-thread workgroup
+        // per CU (the dynamic LDS request is padded past half a CU's LDS so that no CU takes two).  More: two clusters per
+        // XCD, i.e. two workgroups on every CU -- the grid is exactly what the device holds, every workgroup must be resident.
+        const uint32_t C = (uint32_t)v->xcd_size, quantum = 8 * C;
+        int per_cu = 0;
+        const size_t lds2 = v->xcd_lds + (size_t)p.n * 4;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v->xcd_fn, v->xcd_threads, lds2));
+        const uint32_t rounds = (count > 8 && per_cu >= 2) ? 2u : 1u;
+        const uint32_t max_clusters = std::min<uint32_t>((uint32_t)CLUSTER_MAX, ((uint32_t)cu_count / quantum) * 8 * rounds);
+        const uint32_t want = std::min(count, max_clusters);
+        const uint32_t grid = (want + 7) / 8 * quantum;
+        const size_t lds = grid <= (uint32_t)cu_count ? std::max(lds2, v->xcd_lds_one_per_cu) : lds2;
+        if (ensure(&d_cluster_ws, &cap_cluster_ws, (size_t)max_clusters * v->xcd_ws)) return 1;
+        if (!d_cluster_ctl) {
+            HIP_TRY(hipMalloc((void**)&d_cluster_ctl, sizeof(ClusterCtl) + sizeof(ClusterStatus)));
+            HIP_TRY(hipMemsetAsync(d_cluster_ctl, 0, sizeof(ClusterCtl) + sizeof(ClusterStatus), stream));
+        }
+        HIP_TRY(hipMemsetAsync(d_cluster_ctl, 0, sizeof(ClusterCtl), stream));
+        ClusterCtl* ctl = reinterpret_cast<ClusterCtl*>(d_cluster_ctl);
+        BlindRotateClusterArgs ka{a, reinterpret_cast<unsigned char*>(d_cluster_ws), ctl, reinterpret_cast<ClusterStatus*>(ctl + 1),
+                                  cluster_spin_limit, cluster_test_fault};
+        void* kargs[] = {(void*)&ka};
+        HIP_TRY(hipLaunchKernel(v->xcd_fn, dim3(grid), dim3(v->xcd_threads), kargs, lds, stream));
+        cluster_unchecked = true;
+        return 0;
+    }
+    if (v->cluster_fn && cluster_mode != 0 && (cluster_mode >= 1 || count <= cluster_max_batch) &&
         (uint32_t)cu_count >= 8u * (uint32_t)v->cluster_size) {
         // Several CUs per LWE: the grid is a whole number of 8 * C workgroups (the dispatcher deals workgroups
         // round-robin over the 8 XCDs, the kernel forms its clusters from what each XCD actually received),
@@ -914,19 +965,25 @@ int Engine::ks_pbs_dev(const uint64_t* d_big_in, const uint32_t* d_lut_idx, uint
             HIP_TRY(hipStreamWaitEvent(s, pipe_input_ready, 0));
             pipe_input_ready = nullptr;
         }
-        auto overlaps = [](const char* a_lo, const char* a_hi, const void* b, size_t b_bytes) {
-            const char* b_lo = (const char*)b;
-            return b_lo && a_lo < b_lo + b_bytes && b_lo < a_hi;
+        auto overlaps = [](const char* a_lo, const char* a_hi, const std::vector<ByteRange>& rs) {
+            for (const auto& r : rs)
+                if (a_lo < r.hi && r.lo < a_hi) return true;
+            return false;
         };
-        for (int q = 0; q < ns; q++) {       // calls possibly still in flight on the other streams
-            if (q == slot || !ovl_out[q]) continue;
-            if (overlaps(in_lo, in_hi, ovl_out[q], ovl_bytes[q]) || overlaps(out_lo, out_hi, ovl_out[q], ovl_bytes[q]) ||
-                overlaps(out_lo, out_hi, ovl_in[q], ovl_bytes[q]))
+        for (int q = 0; q < ns; q++) {       // every call of this run on the other streams, not only their latest
+            if (q == slot || !ovl_done[q] || (ovl_ins[q].empty() && ovl_outs[q].empty())) continue;
+            if (overlaps(in_lo, in_hi, ovl_outs[q]) || overlaps(out_lo, out_hi, ovl_outs[q]) || overlaps(out_lo, out_hi, ovl_ins[q]))
                 HIP_TRY(hipStreamWaitEvent(s, ovl_done[q], 0));
         }
-        ovl_in[slot] = d_big_in;
-        ovl_out[slot] = d_big_out;
-        ovl_bytes[slot] = (size_t)count * big * 8;
+        auto remember = [](std::vector<ByteRange>& rs, const char* lo, const char* hi) {
+            for (auto& r : rs)
+                if (r.lo == lo && r.hi == hi) return;
+            if (rs.size() < 32) { rs.push_back({lo, hi}); return; }
+            rs[0].lo = std::min(rs[0].lo, lo);          // many distinct buffers: fold into one conservative range
+            rs[0].hi = std::max(rs[0].hi, hi);
+        };
+        remember(ovl_ins[slot], in_lo, in_hi);
+        remember(ovl_outs[slot], out_lo, out_hi);
         HIP_TRY(hipEventRecord(e4[0], s));
         if (launch_keyswitch(d_big_in, sm, count, s, false, slot)) return 1;
         HIP_TRY(hipEventRecord(e4[1], s));
@@ -1105,6 +1162,7 @@ int Engine::last_kernel_ms(float ms[2]) {
     if (use()) return 1;
     if (ring_used == 0) return fail("no ks_pbs call recorded");
     hipEvent_t* e4 = &ring[((ring_used - 1) % 1024) * 4];
+    if (sync_all_streams()) return 1;
     HIP_TRY(hipEventSynchronize(e4[3]));
     HIP_TRY(hipEventElapsedTime(&ms[0], e4[0], e4[1]));
     HIP_TRY(hipEventElapsedTime(&ms[1], e4[2], e4[3]));
@@ -1113,8 +1171,7 @@ int Engine::last_kernel_ms(float ms[2]) {
 
 int Engine::kernel_times(double total_ms[2], uint32_t* calls, bool reset) {
     if (use()) return 1;
-    if (ks_stream) HIP_TRY(hipStreamSynchronize(ks_stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    if (sync_all_streams()) return 1;       // mode 2 records on every overlap stream
     const size_t nrec = ring_used < 1024 ? ring_used : 1024;
     total_ms[0] = total_ms[1] = 0.0;
     for (size_t c = 0; c < nrec; c++) {
@@ -1158,7 +1215,7 @@ int Engine::sync_all_streams() {
 void Engine::end_pipeline_run() {
     pipe_calls = 0;
     pipe_out[0] = pipe_out[1] = nullptr;
-    for (int q = 0; q < OVL_MAX; q++) ovl_in[q] = ovl_out[q] = nullptr;
+    for (int q = 0; q < OVL_MAX; q++) { ovl_ins[q].clear(); ovl_outs[q].clear(); }
 }
 
 // The cluster kernel never hangs on a hand-over that does not arrive: it gives up, finishes with garbage and says so

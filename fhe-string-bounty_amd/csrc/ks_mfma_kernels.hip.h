@@ -8,7 +8,7 @@
 // carry out of the top digit is the reduction mod 2^64.  Then
 //     sum_r d_r K_r = sum_t 2^(8 t) ( sum_r d_r s_t(r) )            (mod 2^64)
 // and the inner sums are int8 x int8 -> int32 dot products: v_mfma_i32_32x32x32_i8 (|d s| <= 2^13, rows per workgroup
-// <= 2^15: no int32 overflow).  Nothing is rounded anywhere: the result is bit-identical to the reference's loop
+// <= 2^15: no int32 overflow -- the host clamps the K chunk, ks_mfma_max_steps).  Nothing is rounded anywhere: the result is bit-identical to the reference's loop
 // (tests/test_gpu_parity.py::test_keyswitch_bit_exact, golden fixtures).
 //
 // Shapes: M = batch (32-row tiles, one wave each), N = output columns x 8 digit planes (a workgroup owns 32 columns,
@@ -36,6 +36,12 @@ struct KsMfmaGeom {
     uint32_t steps;        // k-steps = ceil(in_dim / (2 * epg))
     uint32_t col_groups;   // ceil(out_size / 32)
 };
+
+// A 16-slot group holds floor(16 / level) whole mask elements: at most 16 levels.
+inline bool ks_mfma_supported(uint32_t level) { return level >= 1 && level <= 16; }
+// K-steps one workgroup may accumulate in int32: 32 slots per step, |digit * key digit| <= 2^(base_log - 1) * 128
+// => 32 * steps * 2^(base_log + 6) < 2^31.
+inline uint32_t ks_mfma_max_steps(uint32_t base_log) { return (1u << (20 - base_log)) - 1u; }
 
 __host__ __device__ inline KsMfmaGeom ks_mfma_geom(uint32_t in_dim, uint32_t out_size, uint32_t level, uint32_t base_log) {
     KsMfmaGeom g;

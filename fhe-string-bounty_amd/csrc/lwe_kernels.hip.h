@@ -1,6 +1,6 @@
 // lwe_kernels.hip.h -- batched LWE keyswitch and LWE linear combinations for gfx950.
 //
-//   keyswitch_kernel   out[b] = (0,...,0,body_b) - sum_i sum_lv digit(b,i,lv) * KSK[i][lv][:]
+//   keyswitch_dot4_kernel   out[b] = (0,...,0,body_b) - sum_i sum_lv digit(b,i,lv) * KSK[i][lv][:]
 //                      Replaces keyswitch_lwe_ciphertext (core_crypto/algorithms/lwe_keyswitch.rs:96-170),
 //                      SignedDecomposer::decompose (commons/math/decomposition/decomposer.rs:98-152,
 //                      iter.rs:37-127) and slice_wrapping_sub_scalar_mul_assign
@@ -10,16 +10,12 @@
 //                      (shortint/server_key/add.rs:520-524, scalar_mul.rs:206-208, scalar_add.rs:211-218,
 //                      bivariate_pbs.rs:167-182) applied to whole batches.
 //
-// Keyswitch mapping (HBM-streaming integer work, no MFMA): a workgroup owns a tile of
-// KS_COLS output columns x KS_S samples x KS_IC input coefficients (the kernel is bound by KSK reads
-// out of L2 / Infinity Cache: 60.9 MB x ceil(B / KS_S) per launch, hence the wide sample tile).  Every KSK row segment is
-// read once per tile with 8-byte-per-lane coalesced loads and reused from a VGPR for KS_S samples;
-// the signed digits of the tile are produced once into LDS and broadcast-read.  Digits are biased
-// to unsigned (d' = d + B/2) so that each multiply-accumulate is one v_mad_u64_u32 plus one
-// v_mul_lo_u32; the bias is removed exactly with (B/2) * sum(KSK rows), accumulated on the fly
-// (ring arithmetic mod 2^64, so the result is bit-identical to the reference's signed loop).
-// Partial sums over input chunks are combined with 64-bit integer atomics: wrapping addition is
-// associative and commutative, hence the result is deterministic and bit-exact.
+// Keyswitch mapping (L2-streaming integer work; the matrix-core form is ks_mfma_kernels.hip.h): a workgroup owns a tile
+// of KS_COLS output columns x S samples x KS_IC input coefficients; the signed digits of the tile are produced once into
+// LDS (biased to unsigned bytes) and broadcast-read, the bias is removed exactly with (B/2) * sum(KSK rows) (a property
+// of the key alone, summed at load time), partial sums over input chunks are combined with 64-bit integer atomics:
+// wrapping addition is associative and commutative, hence the result is deterministic and bit-exact.  (The first
+// generation of this kernel -- two v_mad_u64_u32 per element on the 64-bit key layout -- was retired in round 4.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,87 +23,11 @@
 namespace fhe {
 
 constexpr int KS_COLS = 256;  // threads per workgroup == output columns per tile
-constexpr int KS_S = 16;      // samples per tile (digits of one (i,lv) = one 16-byte LDS broadcast read)
 constexpr int KS_IC = 64;     // input coefficients per tile
 
-struct KeyswitchArgs {
-    const uint64_t* lwe_in;   // [B][in_dim+1]
-    const uint64_t* ksk;      // [in_dim][level][out_size]
-    uint64_t* lwe_out;        // [B][out_size], must be zero-filled before launch
-    uint32_t in_dim, out_size, base_log, level, batch;
-};
-
-__global__ void __launch_bounds__(KS_COLS) keyswitch_kernel(KeyswitchArgs a) {
-    extern __shared__ __align__(16) unsigned char ks_smem[];   // [KS_IC][level][KS_S] biased digits
-    const uint32_t col = blockIdx.x * KS_COLS + threadIdx.x;
-    const uint32_t b0 = blockIdx.y * KS_S;
-    const uint32_t i0 = blockIdx.z * KS_IC;
-    const uint32_t L = a.level, bl = a.base_log;
-    const uint32_t half = 1u << (bl - 1);
-
-    // ---- digits of this tile -> LDS ----
-    for (uint32_t e = threadIdx.x; e < (uint32_t)(KS_IC * KS_S); e += KS_COLS) {
-        const uint32_t il = e / KS_S, s = e % KS_S;
-        const uint32_t i = i0 + il, b = b0 + s;
-        uint64_t x = 0;
-        if (i < a.in_dim && b < a.batch) x = a.lwe_in[(size_t)b * (a.in_dim + 1) + i];
-        // closest_representable + initial state (decomposer.rs:98-118, iter.rs:45)
-        const uint32_t rep = bl * L;
-        uint64_t t = x >> (63 - rep);
-        uint64_t state = ((t + 1) >> 1) & ((1ull << rep) - 1);
-        const uint64_t mask = (1ull << bl) - 1;
-        for (uint32_t lv = 0; lv < L; lv++) {   // yields level L first (iter.rs:101-127)
-            uint64_t res = state & mask;
-            state >>= bl;
-            uint64_t carry = ((res - 1ull) | state) & res;
-            carry >>= bl - 1;
-            state += carry;
-            const int32_t digit = (int32_t)(uint32_t)res - (int32_t)((uint32_t)carry << bl);
-            ks_smem[((size_t)il * L + lv) * KS_S + s] = (unsigned char)(digit + (int32_t)half);
-        }
-    }
-    __syncthreads();
-
-    uint64_t acc[KS_S];
-#pragma unroll
-    for (int s = 0; s < KS_S; s++) acc[s] = 0;
-    uint64_t sumkv = 0;
-    const bool col_ok = col < a.out_size;
-    const uint32_t ccol = col_ok ? col : 0;
-    const uint32_t icount = min((uint32_t)KS_IC, a.in_dim - i0);
-    const uint64_t* kp = a.ksk + ((size_t)i0 * L) * a.out_size + ccol;
-    for (uint32_t r = 0; r < icount * L; r++) {
-        const uint64_t kv = kp[(size_t)r * a.out_size];
-        uint32_t dw[KS_S / 4];
-#pragma unroll
-        for (int q = 0; q < KS_S / 16; q++) {
-            const uint4 dq = *reinterpret_cast<const uint4*>(ks_smem + (size_t)r * KS_S + q * 16);
-            dw[4 * q + 0] = dq.x; dw[4 * q + 1] = dq.y; dw[4 * q + 2] = dq.z; dw[4 * q + 3] = dq.w;
-        }
-        sumkv += kv;
-#pragma unroll
-        for (int s = 0; s < KS_S; s++) {
-            const uint32_t d = (dw[s >> 2] >> ((s & 3) * 8)) & 0xffu;
-            acc[s] += kv * (uint64_t)d;
-        }
-    }
-    if (!col_ok) return;
-    const uint64_t corr = sumkv * (uint64_t)half;
-#pragma unroll
-    for (int s = 0; s < KS_S; s++) {
-        const uint32_t b = b0 + s;
-        if (b >= a.batch) break;
-        uint64_t v = corr - acc[s];     // -(sum kv*(d + half)) + half*sum kv = -sum kv*d
-        if (blockIdx.z == 0 && col == a.out_size - 1)
-            v += a.lwe_in[(size_t)b * (a.in_dim + 1) + a.in_dim];   // body copied once (:146)
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.lwe_out + (size_t)b * a.out_size + col),
-                  (unsigned long long)v);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// Byte-plane variant.  The multiply-accumulate above issues two v_mad_u64_u32 per (sample, KSK
-// element) and is bound by that instruction.  Exact reformulation with 8-bit dot products:
+// Byte planes.  A 64-bit multiply-accumulate issues two v_mad_u64_u32 per (sample, KSK element) and is bound by
+// that instruction.  Exact reformulation with 8-bit dot products:
 //   KSK[r][col] = sum_t byte_t(r, col) << 8t,      digit' in [0, 2^b] fits a byte as well, so
 //   sum_r KSK[r][col] * d'[r] = sum_t ( sum_r byte_t(r, col) * d'[r] ) << 8t   (mod 2^64)
 // and the inner sums over 4 consecutive rows are one v_dot4_u32_u8 each (u32 accumulators cannot

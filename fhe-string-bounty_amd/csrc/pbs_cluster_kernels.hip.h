@@ -42,7 +42,7 @@ namespace fhe {
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int CLUSTER_MAX = 64;          // clusters a launch can form (256 CUs / 4)
-constexpr int CLUSTER_MAX_MEMBERS = 16;
+constexpr int CLUSTER_MAX_MEMBERS = 32;  // the epoch flags of a cluster share ONE 128-byte line
 constexpr uint32_t CLUSTER_SPIN_LIMIT = 1u << 22;   // polls (~0.5 us each) before a wait gives up
 
 struct ClusterStatus {                   // sticky: the host reads it at its next synchronisation (Engine::cluster_check)
@@ -54,7 +54,10 @@ struct ClusterCtl {                      // zeroed by the host before every laun
     uint32_t error;                      // != 0: a wait timed out (results are garbage, the launch still ends)
     uint32_t pad[30];
     uint32_t xcd_count[8][32];           // tickets per XCD, one 128-byte line each
-    uint32_t flags[CLUSTER_MAX][CLUSTER_MAX_MEMBERS][32];   // epoch flag of every cluster member, a line each
+    uint32_t flags[CLUSTER_MAX][CLUSTER_MAX_MEMBERS];       // epoch flag of every cluster member; one line per cluster
+    // blind_rotate_xcd_kernel (two workgroups per CU): workgroups per compute unit and per "slot" (first / second arrival on its CU)
+    uint32_t slot_count[8][32];          // per XCD: [0] first arrivals, [1] second arrivals; one line each
+    uint32_t cu_count[8][256];           // per XCD and HW_ID{se, sh, cu}
 };
 
 template <int LOGN, int K1, int L>
@@ -100,7 +103,7 @@ struct BlindRotateClusterArgs {
     ClusterCtl* ctl;
     ClusterStatus* status;
     uint32_t spin_limit;         // polls before a wait gives up (CLUSTER_SPIN_LIMIT; tests lower it)
-    uint32_t test_fault;         // tests only: member 1 of cluster 0 never publishes its flag of this epoch (0 = off)
+    uint32_t test_fault;         // -DFHESTR_TEST_HOOKS builds only: member 1 of cluster 0 never publishes its flag of this epoch (0 = off)
 };
 
 template <class RSRC>
@@ -130,13 +133,12 @@ __device__ __forceinline__ uint64_t load_sc1_b64(RSRC rsrc, uint32_t voff) {
 // itself.  A wave that sees all C flags at this epoch knows that every wave of every member -- its own workgroup's
 // included -- has finished the phase, so the LDS planes may be reused as well.  The C flags of a cluster share one
 // 128-byte line (byte-masked stores into L2; one request per poll).
-template <int C, int PREFETCHED = 0>
+template <int C, int PREFETCHED = 0, uint32_t WAVES = 8>
 __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, uint32_t& epoch, uint32_t* s_dead_generic,
                                              ClusterCtl* ctl, ClusterStatus* status, uint32_t spin_limit, uint32_t mute_epoch) {
     typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32_t;
     lds_vu32_t* s_dead = (lds_vu32_t*)(uintptr_t)lds_address(s_dead_generic);
     const uint32_t arrive_address = lds_address(s_dead_generic + 1);          // the arrival counter sits behind the dead word
-    constexpr uint32_t WAVES = 8;                                             // 512 threads
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PREFETCHED) : "memory");         // this wave's stores have reached L2
     ++epoch;
     if (*s_dead) return;
@@ -167,7 +169,7 @@ __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, u
     asm volatile("" ::: "memory");
 }
 #else
-template <int C, int PREFETCHED = 0>
+template <int C, int PREFETCHED = 0, uint32_t WAVES = 8>
 __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, uint32_t& epoch, uint32_t* s_dead_generic,
                                              ClusterCtl* ctl, ClusterStatus* status, uint32_t spin_limit, uint32_t mute_epoch) {
     typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32_t;     // a plain LDS access (a generic pointer would be a
@@ -200,6 +202,96 @@ __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, u
 
 #endif
 
+// Cluster formation, by ONE thread of every workgroup (agent-scope atomics: valid wherever the workgroups landed): a
+// ticket from the counter of the XCD this workgroup runs on, a grid-wide arrival count, then clusters = runs of C
+// consecutive tickets of one XCD.  s_form: [0] cluster index (0xFFFFFFFF: not part of a complete cluster), [1] member
+// index, [2] clusters the launch formed.  A grid that never becomes resident as a whole raises error 2 and forms nothing.
+template <int C>
+__device__ __forceinline__ void cluster_join(ClusterCtl* ctl, ClusterStatus* status, uint32_t spin_limit, uint32_t* s_form, uint32_t* s_sync) {
+    s_sync[0] = 0;
+    s_sync[1] = 0;
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    const uint32_t ticket = __hip_atomic_fetch_add(&ctl->xcd_count[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&ctl->arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t spins = 0;
+    bool ok = true;
+    while (__hip_atomic_load(&ctl->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+        if (++spins > (spin_limit > (1u << 16) ? spin_limit : (1u << 16))) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    uint32_t base = 0, total = 0, mine = 0;
+    for (uint32_t x = 0; x < 8; x++) {
+        const uint32_t formed = __hip_atomic_load(&ctl->xcd_count[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (uint32_t)C;
+        if (x < xcc) base += formed;
+        if (x == xcc) mine = formed;
+        total += formed;
+    }
+    if (!ok) {
+        __hip_atomic_store(&ctl->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&status->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        total = 0;
+    }
+    const uint32_t local = ticket / (uint32_t)C;
+    const bool member_of_one = ok && local < mine && base + local < (uint32_t)CLUSTER_MAX;
+    s_form[0] = member_of_one ? base + local : 0xFFFFFFFFu;
+    s_form[1] = ticket % (uint32_t)C;
+    s_form[2] = total < (uint32_t)CLUSTER_MAX ? total : (uint32_t)CLUSTER_MAX;
+    if (blockIdx.x == 0) status->clusters = s_form[2];
+}
+
+// Formation for two workgroups per compute unit (blind_rotate_xcd_kernel): the XCD's two clusters should each have ONE
+// workgroup on every CU, so that a CU always has the other LWE to work on while one waits for a hand-over.  (Consecutive
+// tickets put both workgroups of 74 of 256 CUs into the same cluster: those CUs then do a double share of one cluster's
+// phase and every hand-over of that cluster waits for them.)  A workgroup therefore also counts itself in on its CU
+// (HW_ID se/sh/cu): first arrival -> the XCD's cluster 0, second -> cluster 1, member = rank among the arrivals of that
+// kind.  If an XCD's counts are not exactly (C, C) or (C, 0) -- some CU was busy with another kernel -- that XCD falls
+// back to consecutive tickets; every workgroup of the XCD reads the same counts and takes the same decision.
+template <int C>
+__device__ __forceinline__ void cluster_join_per_cu(ClusterCtl* ctl, ClusterStatus* status, uint32_t spin_limit, uint32_t* s_form, uint32_t* s_sync) {
+    s_sync[0] = 0;
+    s_sync[1] = 0;
+    uint32_t xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    xcc &= 7u;
+    const uint32_t cu = (hw >> 8) & 0xFFu;
+    const uint32_t ticket = __hip_atomic_fetch_add(&ctl->xcd_count[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t slot = __hip_atomic_fetch_add(&ctl->cu_count[xcc][cu], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t rank = slot < 2 ? __hip_atomic_fetch_add(&ctl->slot_count[xcc][slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFu;
+    __hip_atomic_fetch_add(&ctl->arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t spins = 0;
+    bool ok = true;
+    while (__hip_atomic_load(&ctl->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+        if (++spins > (spin_limit > (1u << 16) ? spin_limit : (1u << 16))) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    uint32_t base = 0, total = 0, mine = 0;
+    bool mine_by_cu = false;
+    for (uint32_t x = 0; x < 8; x++) {
+        const uint32_t t = __hip_atomic_load(&ctl->xcd_count[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t s0 = __hip_atomic_load(&ctl->slot_count[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t s1 = __hip_atomic_load(&ctl->slot_count[x][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool by_cu = s0 == (uint32_t)C && (s1 == (uint32_t)C || s1 == 0u) && t == s0 + s1;
+        const uint32_t formed = by_cu ? (s1 ? 2u : 1u) : t / (uint32_t)C;
+        if (x < xcc) base += formed;
+        if (x == xcc) { mine = formed; mine_by_cu = by_cu; }
+        total += formed;
+    }
+    if (!ok) {
+        __hip_atomic_store(&ctl->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&status->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        total = 0;
+    }
+    const uint32_t local = mine_by_cu ? slot : ticket / (uint32_t)C;
+    const bool member_of_one = ok && local < mine && base + local < (uint32_t)CLUSTER_MAX;
+    s_form[0] = member_of_one ? base + local : 0xFFFFFFFFu;
+    s_form[1] = mine_by_cu ? rank : ticket % (uint32_t)C;
+    s_form[2] = total < (uint32_t)CLUSTER_MAX ? total : (uint32_t)CLUSTER_MAX;
+    if (blockIdx.x == 0) status->clusters = s_form[2];
+}
+
 template <int LOGN, int K1, int L>
 __global__ void __launch_bounds__((BrClusterCfg<LOGN, K1, L>::THREADS))
 blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
@@ -219,39 +311,7 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
     const int tid = threadIdx.x;
 
     // ---- cluster formation (agent-scope atomics: valid wherever the workgroups landed) ----
-    if (tid == 0) {
-        s_sync[0] = 0;
-        s_sync[1] = 0;
-        uint32_t xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        xcc &= 7u;
-        const uint32_t ticket = __hip_atomic_fetch_add(&ctl->xcd_count[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&ctl->arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t spins = 0;
-        bool ok = true;
-        while (__hip_atomic_load(&ctl->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-            if (++spins > (ca.spin_limit > (1u << 16) ? ca.spin_limit : (1u << 16))) { ok = false; break; }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        uint32_t base = 0, total = 0, mine = 0;
-        for (uint32_t x = 0; x < 8; x++) {
-            const uint32_t formed = __hip_atomic_load(&ctl->xcd_count[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (uint32_t)C;
-            if (x < xcc) base += formed;
-            if (x == xcc) mine = formed;
-            total += formed;
-        }
-        if (!ok) {
-            __hip_atomic_store(&ctl->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ca.status->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            total = 0;
-        }
-        const uint32_t local = ticket / (uint32_t)C;
-        const bool member_of_one = ok && local < mine && base + local < (uint32_t)CLUSTER_MAX;
-        s_form[0] = member_of_one ? base + local : 0xFFFFFFFFu;
-        s_form[1] = ticket % (uint32_t)C;
-        s_form[2] = total < (uint32_t)CLUSTER_MAX ? total : (uint32_t)CLUSTER_MAX;
-        if (blockIdx.x == 0) ca.status->clusters = s_form[2];
-    }
+    if (tid == 0) cluster_join<C>(ctl, ca.status, ca.spin_limit, s_form, s_sync);
     __syncthreads();
     const uint32_t cluster = s_form[0], member = s_form[1], n_clusters = s_form[2];
     if (cluster == 0xFFFFFFFFu) return;          // not part of a complete cluster: the whole workgroup leaves
@@ -328,9 +388,13 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
         const int u = hB * UH + uu, it = u / K1, row = u % K1;
         voff_key[uu] = (uint32_t)(((((L - 1 - it) * K1 + row) * K1) * P + rowA * P2 + tauB) * 16);
     }
-    uint32_t* flags = &ctl->flags[cluster][0][0];
+    uint32_t* flags = &ctl->flags[cluster][0];
     uint32_t epoch = 0;
+#ifdef FHESTR_TEST_HOOKS
     const uint32_t mute_epoch = (ca.test_fault && cluster == 0 && member == 1) ? ca.test_fault : 0u;
+#else
+    const uint32_t mute_epoch = 0u;
+#endif
 
     const uint32_t n = args.n;
     const uint32_t bL = args.base_log * L;

@@ -146,7 +146,7 @@ EXPORTS = [
     "fhe_plan_create", "fhe_plan_destroy", "fhe_plan_input", "fhe_plan_lut", "fhe_plan_lin", "fhe_plan_pbs",
     "fhe_plan_output", "fhe_plan_finalize", "fhe_plan_info", "fhe_plan_level_info", "fhe_plan_export_level",
     "fhe_plan_run", "fhe_plan_run_level_rank_dev", "fhe_plan_gather_outputs_dev", "fhe_str_plan_create",
-    "fhe_plan_level_rank_info", "fhe_plan_noise_info", "fhe_noise_model", "fhe_noise_model_is_calibrated", "fhe_plan_set_noise_budget",
+    "fhe_plan_level_rank_info", "fhe_plan_noise_info", "fhe_noise_model", "fhe_noise_model_is_calibrated", "fhe_params_supported", "fhe_plan_set_noise_budget",
     "fhe_host_alloc", "fhe_host_free",
     "fhe_plan_pbs_signed", "fhe_plan_pbs_full_box", "fhe_plan_set_owner_hint",
     "fhe_str_to_upper", "fhe_str_to_lower", "fhe_plan_create_offline", "fhe_str_plan_create_offline",
@@ -247,6 +247,7 @@ def lib() -> C.CDLL:
     sig("fhe_plan_noise_info", vp, C.POINTER(C.c_double))
     sig("fhe_noise_model", PP, C.POINTER(C.c_double))
     sig("fhe_noise_model_is_calibrated", PP)
+    sig("fhe_params_supported", PP)
     sig("fhe_host_alloc", C.c_size_t, C.POINTER(vp))
     sig("fhe_host_free", vp)
     sig("fhe_plan_set_noise_budget", vp, C.c_double)
@@ -319,6 +320,13 @@ def pinned_empty(shape, dtype=np.uint64):
     arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
     weakref.finalize(buf, lib().fhe_host_free, C.c_void_p(ptr.value))
     return arr
+
+
+def params_supported(params: "Params"):
+    """(True, "") if fhe_engine_create would accept the parameters, else (False, reason).  Needs no device."""
+    if lib().fhe_params_supported(C.byref(params.c())) == 0:
+        return True, ""
+    return False, lib().fhe_last_error().decode()
 
 
 def noise_model_is_calibrated(params: "Params") -> bool:

@@ -112,10 +112,14 @@ int fhe_engine_pipeline_input_event(fhe_engine *eng, void *hip_event);
  * max_batch * (n / grouping_factor) * (k+1)^2 * N * 8 bytes of device workspace when used. */
 int fhe_engine_set_multibit_combine_max(fhe_engine *eng, uint32_t max_batch);
 /* Polynomial sizes N >= 16384 (PARAM_MESSAGE_4_CARRY_4 ...): the blind rotation of one LWE is spread over a
- * cluster of compute units of one XCD (8 for N = 32768, 4 for N = 16384) that exchange the four-step transform's
- * matrices through that XCD's L2.  mode: -1 automatic (default; env FHESTR_CLUSTER), 0 never (one workgroup per
- * LWE through an HBM workspace), 1 always; max_batch: in automatic mode, batches above it take the one-workgroup
- * kernel.  Both kernels read the same Fourier key and give decrypt-identical results. */
+ * cluster of compute units of one XCD that exchange the four-step transform's matrices through that XCD's L2:
+ * all 32 CUs of the XCD with two LWEs in flight per XCD for N = 32768 with two levels (round 4), 8 / 4 CUs
+ * (N = 32768 / 16384) otherwise.  mode: -1 automatic (default; env FHESTR_CLUSTER), 0 never (one workgroup per
+ * LWE through an HBM workspace), 1 always, 2 always and with round 3's 8-CU clusters even where the whole-XCD
+ * kernel exists; max_batch: in automatic mode, batches above it take the one-workgroup kernel.  Automatic mode
+ * picks the whole-XCD kernel for up to 16 LWEs (one LWE: 12.3 ms against 20.9 ms) and the 8-CU clusters above
+ * (four LWEs in flight per XCD: 1.15 k PBS/s at 256 LWEs against 0.85 k).  All kernels read the same Fourier key
+ * and give decrypt-identical results. */
 int fhe_engine_set_cluster_mode(fhe_engine *eng, int mode, uint32_t max_batch);
 /* Latency knob for dependent chains of small batches (the trailing levels of a string comparison): with `on`, a
  * blind-rotation launch that would leave more than half of the compute units idle carries replicas of its workgroups
@@ -226,6 +230,12 @@ int fhe_host_free(void *ptr);
 /* 1 if the model's PBS-output variance has been checked against this engine's measured noise for the shape
  * (N, k, level, grouping factor) of `params`; shapes that have not carry a 4x safety factor in the budget. */
 int fhe_noise_model_is_calibrated(const fhe_params_t *params);
+/* Would fhe_engine_create accept these parameters?  0 = yes; 1 = no, reason in fhe_last_error.  Needs no device: the
+ * same checks fhe_engine_create runs before it touches one (a blind-rotation kernel instantiated for (N, k, level,
+ * grouping factor); decomposition ranges of the keyswitch -- any level count, more than 16 levels take the byte-plane
+ * kernel instead of the matrix-core one).  Covers every ClassicPBSParameters / MultiBitPBSParameters constant of
+ * shortint/parameters/{mod,multi_bit,parameters_compact_pk}.rs (tests/test_parameter_tables.py). */
+int fhe_params_supported(const fhe_params_t *params);
 /* Pool layout of a level.  Every rank runs its own jobs [job_lo, job_hi) of the level (rank_info) and
  * writes job job_lo + i to pool slot local_base + i; if e_max > 0 the level ends with an all-gather of
  * the first e_max slots of every rank's local region into [recv_base, recv_base + world * e_max).

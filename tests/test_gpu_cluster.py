@@ -15,6 +15,11 @@ import os as _os
 ROOT_DIR = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
 
 SHAPES = [O.TOY_N32768] + [p for p in O.TOY_SHAPES if p.N >= 16384]
+# (shape, fhe_engine_set_cluster_mode): 1 = the best multi-CU kernel of the shape -- blind_rotate_xcd_kernel (all CUs of an
+# XCD per LWE, csrc/pbs_xcd_kernels.hip.h) for N = 32768 with two levels, blind_rotate_cluster_kernel otherwise; 2 = the
+# 8-CU cluster kernel also where the whole-XCD kernel exists
+CASES = [(p, 1) for p in SHAPES] + [(O.TOY_N32768, 2)]
+CASE_IDS = [f"{p.name}-mode{m}" for p, m in CASES]
 
 
 def _phases(ks, cts):
@@ -27,15 +32,15 @@ def _tolerance(p):
     return 8.0 * np.sqrt(2.0 * v_pbs) * 2.0**64
 
 
-@pytest.mark.parametrize("params", SHAPES, ids=lambda p: p.name)
-def test_cluster_kernel_against_oracle(params):
+@pytest.mark.parametrize("params,mode", CASES, ids=CASE_IDS)
+def test_cluster_kernel_against_oracle(params, mode):
     ks = keyset(params)
     eng = gpu_engine(ks)
     M = params.msg_mod * params.carry_mod
     f = lambda x: (3 * x + 1) % M
     lut, _ = ks.sk.generate_lookup_table(f)
     lut_id = eng.upload_lut(lut)
-    eng.set_cluster_mode(1)
+    eng.set_cluster_mode(mode)
     try:
         # zero-mask PBS (no CMUX step runs: LUT rotation, hand-over of the published accumulator, sample extraction)
         small = np.zeros((4, params.small_size), dtype=np.uint64)
@@ -64,15 +69,16 @@ def test_cluster_kernel_against_oracle(params):
         eng.set_cluster_mode(-1)
 
 
-@pytest.mark.parametrize("params", [O.TOY_N32768, [p for p in O.TOY_SHAPES if p.N == 16384][0]], ids=lambda p: p.name)
-def test_cluster_kernel_more_lwes_than_clusters(params):
+@pytest.mark.parametrize("params,mode", [(O.TOY_N32768, 1), (O.TOY_N32768, 2), ([p for p in O.TOY_SHAPES if p.N == 16384][0], 1)],
+                         ids=lambda v: getattr(v, "name", str(v)))
+def test_cluster_kernel_more_lwes_than_clusters(params, mode):
     """Every cluster walks several LWEs (epoch flags, workspace and mask table reused), ragged count, two tables."""
     ks = keyset(params)
     eng = gpu_engine(ks)
     M = params.msg_mod * params.carry_mod
     fs = [lambda x: (3 * x + 1) % M, lambda x: (M - 1 - x)]
     ids = [eng.upload_lut(ks.sk.generate_lookup_table(f)[0]) for f in fs]
-    eng.set_cluster_mode(1)
+    eng.set_cluster_mode(mode)
     try:
         B = 2 * 64 + 3
         rng = np.random.default_rng(17)
@@ -94,14 +100,20 @@ def test_cluster_kernel_more_lwes_than_clusters(params):
         eng.set_cluster_mode(-1)
 
 
-def test_a_missing_hand_over_is_reported_not_hung():
-    """Fault injection (FHESTR_CLUSTER_TEST_FAULT): one workgroup of one cluster never publishes one of its epoch flags.
-    The waits of that cluster give up after the (lowered) poll limit, the launch drains, the next host-visible
-    completion point returns an error -- and the engine is usable again afterwards.  A hand-over that never comes
-    must never hang the GPU."""
+TESTHOOKS_LIB = _os.path.join(ROOT_DIR, "build", "testhooks", "libfhestr_testhooks.so")
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_a_missing_hand_over_is_reported_not_hung(mode):
+    """Fault injection: one workgroup of one cluster never publishes one of its epoch flags.  The waits of that cluster
+    give up after the (lowered) poll limit, the launch drains, the next host-visible completion point returns an error
+    -- and the engine is usable again afterwards.  A hand-over that never comes must never hang the GPU.
+    The hook (FHESTR_CLUSTER_TEST_FAULT) exists only in the -DFHESTR_TEST_HOOKS build of the library
+    (`make -C fhe-string-bounty_amd testhooks`, built by __graft_entry__.build()); the product library ignores it."""
     import os
     import subprocess
     import sys
+    assert os.path.exists(TESTHOOKS_LIB), "build/testhooks/libfhestr_testhooks.so missing: run __graft_entry__.build()"
     code = r'''
 import sys, numpy as np
 sys.path.insert(0, "fhe-string-bounty_amd"); sys.path.insert(0, ".")
@@ -114,18 +126,22 @@ eng = fhestr.Engine(to_fhestr_params(p), 0); eng.load_keys(sk.bsk, sk.ksk)
 M = p.msg_mod * p.carry_mod
 lut, _ = eng.generate_lookup_table(lambda x: (x + 1) % M)
 cts = ck.encrypt_many([1, 2, 3], O.Rng(1, 1))
-eng.set_cluster_mode(1)
+eng.set_cluster_mode(int(sys.argv[1]))
 try:
     eng.apply_lookup_table(cts, np.full(3, lut, dtype=np.uint32))
     print("NO ERROR")
 except fhestr.FheError as e:
     print("ERROR:", e)
 '''
-    env = dict(os.environ, FHESTR_CLUSTER_TEST_FAULT="5", FHESTR_CLUSTER_SPIN_LIMIT="4096")
-    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT_DIR, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
+    base = {k: v for k, v in os.environ.items() if k not in ("FHESTR_LIB", "FHESTR_CLUSTER_TEST_FAULT")}
+    hooks = dict(base, FHESTR_LIB=TESTHOOKS_LIB, FHESTR_CLUSTER_TEST_FAULT="5", FHESTR_CLUSTER_SPIN_LIMIT="4096")
+    r = subprocess.run([sys.executable, "-c", code, str(mode)], env=hooks, cwd=ROOT_DIR, capture_output=True, text=True, timeout=300)
     assert "ERROR:" in r.stdout and "hand-over timed out" in r.stdout, r.stdout + r.stderr[-1000:]
-    # the same engine configuration without the fault still works (fresh process: the fault hook is an env switch)
-    env.pop("FHESTR_CLUSTER_TEST_FAULT")
-    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT_DIR, capture_output=True, text=True, timeout=300)
-    assert "NO ERROR" in r.stdout, r.stdout + r.stderr[-1000:]
+    # the product library has no such hook: the same environment runs clean
+    prod = dict(base, FHESTR_CLUSTER_TEST_FAULT="5", FHESTR_CLUSTER_SPIN_LIMIT="4096")
+    r = subprocess.run([sys.executable, "-c", code, str(mode)], env=prod, cwd=ROOT_DIR, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "NO ERROR" in r.stdout, r.stdout + r.stderr[-1000:]
+    # and the test build without the fault works too
+    hooks.pop("FHESTR_CLUSTER_TEST_FAULT")
+    r = subprocess.run([sys.executable, "-c", code, str(mode)], env=hooks, cwd=ROOT_DIR, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "NO ERROR" in r.stdout, r.stdout + r.stderr[-1000:]
