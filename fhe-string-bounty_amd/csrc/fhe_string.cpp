@@ -604,8 +604,18 @@ public:
         for (size_t o = 0; o < n; o++) {
             const size_t b = o / Fb, r = o % Fb;
             std::vector<Term> t{{match[o], 1}};
-            if (r > 0) t.push_back({within[o - 1], 2});
-            if (b > 0) t.push_back({block_pre[b - 1], 4});
+            if (T >= 8) {
+                if (r > 0) t.push_back({within[o - 1], 2});
+                if (b > 0) t.push_back({block_pre[b - 1], 4});
+            } else if (r > 0 && b > 0) {
+                // boxes of fewer than 8 values (PARAM_MESSAGE_1_CARRY_1: T = 4) cannot hold the three bits side by side
+                // (ADVICE r3): the two "before" bits are OR-ed by one more lookup, then match + 2 * before <= 3
+                t.push_back({c.pbs(c.lin({{within[o - 1], 1}, {block_pre[b - 1], 1}}), nz), 2});
+            } else if (r > 0) {
+                t.push_back({within[o - 1], 2});
+            } else if (b > 0) {
+                t.push_back({block_pre[b - 1], 2});
+            }
             first[o] = t.size() == 1 ? match[o] : c.pbs(c.lin(t), first_lut);
         }
         if (from_end) std::reverse(first.begin(), first.end());   // one-hot vector back on the original offsets

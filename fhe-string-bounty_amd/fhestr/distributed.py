@@ -93,6 +93,7 @@ class GpuBackend:
         stream = self.torch.cuda.current_stream(self.device)
         if n_outputs * self.big * 8 < (4 << 20):
             stream.synchronize()
+            self._check_engine()
             return out.cpu().numpy().view(np.uint64)
         # large outputs (to_lower / replace on 1024 chars: 67 MB): a pageable download runs at 3 GB/s; stage through a
         # page-locked buffer kept by the backend (full PCIe rate) and hand out a copy
@@ -101,4 +102,11 @@ class GpuBackend:
             host = self._host_out = self.torch.empty((n_outputs, self.big), dtype=self.torch.int64, pin_memory=True)
         host.copy_(out, non_blocking=True)
         stream.synchronize()
+        self._check_engine()
         return host.numpy().view(np.uint64).copy()
+
+    def _check_engine(self):
+        """Before results leave: the multi-CU blind-rotation kernels (N >= 16384) never hang on a hand-over that does not
+        come (a foreign kernel holding CUs), they finish with garbage and raise a sticky status -- fhe_engine_synchronize
+        reads it and raises (this backend only synchronised torch's stream and returned such outputs silently)."""
+        self.plan.engine.synchronize()

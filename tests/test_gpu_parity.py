@@ -52,6 +52,34 @@ def test_keyswitch_bit_exact(params):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("ks_level,ks_base_log", [(22, 1), (17, 2), (11, 2), (16, 1)])
+def test_keyswitch_with_many_levels_bit_exact(ks_level, ks_base_log):
+    """Keyswitch decompositions of the compact-public-key parameter sets (shortint/parameters/parameters_compact_pk.rs:
+    22 levels of base 2, 11 of base 4, ...) on a toy twin: more than 16 levels do not fit a 16-slot group of the matrix-core
+    kernel and take the byte-plane kernel (they divided by zero at key load), up to 16 take the matrix cores with
+    one mask element per group.  Bit-exact against the oracle, ragged batch; then one KS + PBS round trip."""
+    import fhestr
+    from conftest import to_fhestr_params
+    p = O.Params(8, 1, 256, 15, 2, ks_base_log, ks_level, 4, 1, 1e-13, 1e-17, f"TOY_N256_KS{ks_level}x{ks_base_log}")
+    ck = O.ClientKey(p, 0x5EED0077)
+    sk = O.ServerKey(ck)
+    eng = fhestr.Engine(to_fhestr_params(p), 0)
+    try:
+        eng.load_keys(sk.bsk, sk.ksk)
+        rng = np.random.default_rng(3)
+        cts = rng.integers(0, 2**64, size=(37, p.big_size), dtype=np.uint64)
+        cts[0, :] = 0
+        cts[1, :] = 2**64 - 1
+        assert np.array_equal(eng.keyswitch(cts), np.stack([sk.keyswitch(c) for c in cts]))
+        M = p.msg_mod * p.carry_mod
+        lut, _ = eng.generate_lookup_table(lambda x: (x + 1) % M)
+        enc = ck.encrypt_many(list(range(M)) * 3)
+        out = eng.apply_lookup_table(enc, np.full(len(enc), lut, dtype=np.uint32))
+        assert np.array_equal(ck.decrypt_many(out), np.array([(m + 1) % M for m in list(range(M)) * 3]))
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("params", PARAM_SETS, ids=lambda p: p.name)
 def test_lut_generation_matches_oracle(params):
     ks = keyset(params)
@@ -517,6 +545,49 @@ def test_overlapped_batches_mode_matches_the_large_batch_kernel(p22):
     assert all(np.array_equal(a, b) for a, b in zip(wide_serial, overlapped))
     dec = lambda arrs: [ks.ck.decrypt_many(a.view(np.uint64)) for a in arrs]
     assert all(np.array_equal(a, b) for a, b in zip(dec(default_serial), dec(overlapped)))
+
+
+@pytest.mark.gpu
+def test_overlapped_mode_three_interleaved_dependent_chains(p22):
+    """mode 2 used to remember only the LAST call of each stream.  Three chains interleaved call by call
+    (A0 B0 C0 A1 B1 C1 ...) put chain A's calls on streams 0, 1, 0, 1 ...: A1 (stream 1) reads what A0 (stream 0) wrote three
+    calls earlier, by which time stream 0's record described C0 -- the wait was skipped.  Every call of the run is remembered now.  Bit-identical to the same calls made serially on the same kernel, several times over."""
+    import torch
+    ks = p22
+    eng = gpu_engine(ks)
+    p = ks.params
+    M = p.msg_mod * p.carry_mod
+    lut, _ = eng.generate_lookup_table(lambda x: (5 * x + 2) % M)
+    rng = np.random.default_rng(31)
+    B = 96
+    heads = [torch.from_numpy(ks.ck.encrypt_many(rng.integers(0, M, size=B)).view(np.int64)).cuda() for _ in range(3)]
+    idx = torch.full((B,), int(lut), dtype=torch.int32, device="cuda")
+    depth = 4
+
+    def run(mode):
+        eng.set_pipeline(mode)
+        bufs = [[torch.zeros_like(h) for _ in range(depth)] for h in heads]
+        for d in range(depth):
+            for c in range(3):
+                src = heads[c] if d == 0 else bufs[c][d - 1]
+                eng.apply_lookup_table_dev(src.data_ptr(), idx.data_ptr(), bufs[c][d].data_ptr(), B)
+        eng.synchronize()
+        eng.set_pipeline(0)
+        return [b.cpu().numpy() for chain in bufs for b in chain]
+
+    eng.set_variant(16 | 2)                 # the serial reference on the kernel mode 2 uses
+    try:
+        want = run(0)
+        for _ in range(5):
+            got = run(2)
+            assert all(np.array_equal(a, b) for a, b in zip(want, got))
+    finally:
+        eng.set_variant(0)
+    f = lambda x: (5 * x + 2) % M
+    msgs = ks.ck.decrypt_many(heads[0].cpu().numpy().view(np.uint64))
+    for d in range(depth):
+        msgs = np.array([f(int(m)) for m in msgs])
+        assert np.array_equal(ks.ck.decrypt_many(want[d].view(np.uint64)), msgs)
 
 
 @pytest.mark.gpu

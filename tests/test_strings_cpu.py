@@ -609,3 +609,25 @@ def test_replace_occurrence_recurrence_two_offsets_per_level(toy_k1, s, frm):
     plan = _plan(f"replace:3:{cap}", cap, 6)
     inputs = np.concatenate([_enc(toy_k1, s, cap), _enc(toy_k1, frm, 3), _enc(toy_k1, to, 3)])
     assert fhestr.blocks_to_string(P, toy_k1.ck.decrypt_many(run_with_oracle(plan, inputs, toy_k1.sk))) == want
+
+
+@pytest.mark.parametrize("s,pat", [(b"xxxxab", b"ab"), (b"abxxab", b"ab"), (b"xxxxxx", b"ab"), (b"xabab", b"ab")])
+def test_find_on_one_bit_blocks(s, pat):
+    """PARAM_MESSAGE_1_CARRY_1's box holds T = 4 values: find's first-hit test cannot read (match, hit earlier in the run,
+    hit in an earlier run) side by side there (find_clear was refused with 'input degree 5 overflows'); the two
+    "before" bits are OR-ed first.  Toy twin of the set (N = 512, k = 3), oracle-executed.  Encrypted patterns pack two
+    pattern characters per lookup and need a box of 16 values: on this set they are refused at plan build, cleanly."""
+    import fhestr
+    p = next(q for q in O.TOY_SHAPES if q.name == "TOY_N512_K3")
+    assert p.msg_mod * p.carry_mod == 4
+    ks = keyset(p)
+    P = to_fhestr_params(p)
+    inputs = ks.ck.encrypt_many(fhestr.string_to_blocks(P, s, 6))
+    for op in ("find", "rfind"):
+        idx = s.find(pat) if op == "find" else s.rfind(pat)
+        plan = fhestr.Plan.string_op(None, op + "_clear", 6, 0, pat, 1, params=P)
+        out = ks.ck.decrypt_many(run_with_oracle(plan, inputs, ks.sk)).tolist()
+        got = sum(d * P.msg_mod**i for i, d in enumerate(out[1:]))
+        assert out[0] == int(idx >= 0) and (idx < 0 or got == idx), (op, out, idx)
+    with pytest.raises(fhestr.FheError, match="overflows"):
+        fhestr.Plan.string_op(None, "find", 6, 2, None, 1, params=P)
