@@ -248,6 +248,51 @@ def bench_strings(fhestr, eng, ck, P, rank, world, local_rank, reps=3, staged=Fa
             eng.set_keep_busy(False)
             plan.close()
     eng.set_stream(None)
+    # ---- many strings per pass (fhe_plan_run_batch): level l of all instances is ONE launch.  A single eq pays four
+    #      dependent single-PBS latencies on a nearly idle GPU; M of them share those four.  With several GPUs the
+    #      instances shard over the ranks (every rank runs its own M here): no collective at all. ----
+    try:
+        import torch.distributed as dist
+        batch_cases = [("eq_256_batch8", "eq", 256, 256, 8), ("eq_256_batch32", "eq", 256, 256, 32),
+                       ("contains_16_in_256_batch8", "contains", 256, 16, 8)]
+        for name, op, a_cap, b_cap, M in batch_cases:
+            plan = fhestr.Plan.string_op(eng, op, a_cap, b_cap)
+            rows, want = [], []
+            for i in range(M):
+                if op == "eq":
+                    r = hay if i % 2 == 0 else bytes(bytearray(hay[:i]) + bytearray([hay[i] ^ 1]) + bytearray(hay[i + 1:]))
+                    rows.append(np.concatenate([enc(r, a_cap), enc(hay, b_cap)]))
+                    want.append(int(r == hay))
+                else:
+                    r = hay if i % 2 == 0 else hay[:off] + bytes([hay[off] ^ 1]) + hay[off + 1:]
+                    rows.append(np.concatenate([enc(r, a_cap), enc(pat, b_cap)]))
+                    want.append(int(pat in r))
+            d_in = torch.from_numpy(np.stack(rows).view(np.int64)).to(dev)
+            info = plan.info()
+            d_out = torch.zeros((M, info["n_outputs"], P.big_size), dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            n_rep = 3
+            for it in range(1 + n_rep):
+                if it == 1:
+                    eng.synchronize()
+                    if world > 1:
+                        dist.barrier()
+                    t0 = time.perf_counter()
+                plan.run_batch_dev(d_in.data_ptr(), d_out.data_ptr(), M)
+            eng.synchronize()
+            dt = (time.perf_counter() - t0) / n_rep
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device="cpu" if staged else dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            got = [int(v) for v in ck.decrypt(d_out.cpu().numpy().view(np.uint64)[:, 0])]
+            out[name] = {"ms_per_op": dt * 1e3 / (M * world), "ms_per_pass": dt * 1e3, "instances_per_rank": M, "instances_sharded_over": world,
+                         "collectives_per_op": 0, "n_pbs_per_op": info["n_pbs"], "levels": info["n_levels"],
+                         "pbs_per_s": info["n_pbs"] * M * world / dt, "correct": got == want}
+            plan.close()
+            del d_in, d_out
+    except Exception as e:      # secondary section
+        out["batch_error"] = f"{type(e).__name__}: {e}"
     return out
 
 
@@ -765,7 +810,9 @@ def main():
             rec["string_ops"] = string_ops
             # first-class: FheString ms/op with every level's jobs sharded over the `world` ranks
             for key, field in (("eq_256_enc_enc", "fhestring_eq_256_ms"), ("contains_16_in_256_enc_enc", "fhestring_contains_16_in_256_ms"),
-                               ("eq_256_enc_enc_keep_busy", "fhestring_eq_256_keep_busy_ms")):
+                               ("eq_256_enc_enc_keep_busy", "fhestring_eq_256_keep_busy_ms"),
+                               ("eq_256_batch8", "fhestring_eq_256_batch8_ms_per_op"), ("eq_256_batch32", "fhestring_eq_256_batch32_ms_per_op"),
+                               ("contains_16_in_256_batch8", "fhestring_contains_16_in_256_batch8_ms_per_op")):
                 if isinstance(string_ops.get(key), dict):
                     rec[field] = string_ops[key]["ms_per_op"]
 

@@ -618,6 +618,26 @@ int fhe_plan_run(fhe_plan* p, const uint64_t* inputs, uint64_t* outputs) {
     API_END
 }
 
+int fhe_plan_run_batch(fhe_plan* p, uint32_t instances, const uint64_t* inputs, uint64_t* outputs) {
+    API_BEGIN
+    PLAN_READY(p);
+    if (instances == 0) return 0;
+    CHECK_PTR(outputs);
+    if (p->c->n_inputs()) CHECK_PTR(inputs);
+    return p->c->run_batch_host(inputs, p->c->n_inputs(), nullptr, outputs, instances);
+    API_END
+}
+
+int fhe_plan_run_batch_dev(fhe_plan* p, uint32_t instances, const uint64_t* d_inputs, uint64_t* d_outputs) {
+    API_BEGIN
+    PLAN_READY(p);
+    if (instances == 0) return 0;
+    CHECK_PTR(d_outputs);
+    if (p->c->n_inputs()) CHECK_PTR(d_inputs);
+    return p->c->run_batch_dev(d_inputs, d_outputs, instances);
+    API_END
+}
+
 int fhe_plan_run_level_rank_dev(fhe_plan* p, uint64_t* d_pool, uint32_t level, uint32_t rank) {
     API_BEGIN
     PLAN_READY(p); CHECK_PTR(d_pool);
@@ -632,17 +652,9 @@ int fhe_plan_gather_outputs_dev(fhe_plan* p, const uint64_t* d_pool, uint64_t* d
     API_END
 }
 
-// one-call FheString operations (host buffers): up to three encrypted operands, each `caps[i]` characters
-static int str_op_parts(fhe_engine* eng, const std::string& op, const uint64_t* const* operands, const uint32_t* caps,
-                        uint32_t n_operands, const uint8_t* clear, uint32_t clear_len, uint64_t* out) {
-    API_BEGIN
-    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(out);
-    uint32_t a_cap = caps[0], b_cap = 0;
-    for (uint32_t i = 0; i < n_operands; i++) {
-        CHECK_PTR(operands[i]);
-        if (i) b_cap += caps[i];
-    }
-    // plan cache, most recently used first (at most STR_PLAN_CACHE entries)
+// plan cache of the one-call string operations, most recently used first (at most STR_PLAN_CACHE entries)
+static int cached_str_plan(fhe_engine* eng, const std::string& op, uint32_t a_cap, uint32_t b_cap, const uint8_t* clear, uint32_t clear_len,
+                           fhe_plan** out) {
     constexpr size_t STR_PLAN_CACHE = 8;
     std::string key = op + "|" + std::to_string(a_cap) + "|" + std::to_string(b_cap) + "|";
     if (clear) key.append(reinterpret_cast<const char*>(clear), clear_len);
@@ -662,6 +674,22 @@ static int str_op_parts(fhe_engine* eng, const std::string& op, const uint64_t* 
             cache.pop_back();
         }
     }
+    *out = plan;
+    return 0;
+}
+
+// one-call FheString operations (host buffers): up to three encrypted operands, each `caps[i]` characters
+static int str_op_parts(fhe_engine* eng, const std::string& op, const uint64_t* const* operands, const uint32_t* caps,
+                        uint32_t n_operands, const uint8_t* clear, uint32_t clear_len, uint64_t* out) {
+    API_BEGIN
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(out);
+    uint32_t a_cap = caps[0], b_cap = 0;
+    for (uint32_t i = 0; i < n_operands; i++) {
+        CHECK_PTR(operands[i]);
+        if (i) b_cap += caps[i];
+    }
+    fhe_plan* plan = nullptr;
+    if (cached_str_plan(eng, op, a_cap, b_cap, clear, clear_len, &plan)) return 1;
     const uint32_t bpc = plan->c->n_inputs() / (a_cap + b_cap);      // blocks per character
     uint32_t counts[3] = {0, 0, 0};
     for (uint32_t i = 0; i < n_operands; i++) counts[i] = caps[i] * bpc;
@@ -675,6 +703,23 @@ static int str_op(fhe_engine* eng, const char* op, const uint64_t* a, uint32_t a
     const uint64_t* operands[2] = {a, b};
     const uint32_t caps[2] = {a_cap, b_cap};
     return str_op_parts(eng, op, operands, caps, b ? 2 : 1, clear, clear_len, out);
+}
+
+// `count` strings against ONE second operand in one pass (Circuit::run_batch_host): level l of all rows is one launch.
+int fhe_str_op_many(fhe_engine* eng, const char* op, const uint64_t* rows, uint32_t a_cap, uint32_t count, const uint64_t* b, uint32_t b_cap,
+                    const uint8_t* clear, uint32_t clear_len, uint64_t* out, uint32_t* n_outputs) {
+    API_BEGIN
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(op);
+    fhe_plan* plan = nullptr;
+    if (cached_str_plan(eng, op, a_cap, b_cap, clear, clear_len, &plan)) return 1;
+    if (n_outputs) *n_outputs = plan->c->n_outputs();
+    if (!out && n_outputs) return 0;                    // query: how many output ciphertexts per row
+    CHECK_PTR(rows); CHECK_PTR(out);
+    if (b_cap && !b) return fail("null pointer: b");
+    if (a_cap + b_cap == 0) return fail("fhe_str_op_many: empty operands");
+    const uint32_t bpc = plan->c->n_inputs() / (a_cap + b_cap);
+    return plan->c->run_batch_host(rows, a_cap * bpc, b_cap ? b : nullptr, out, count);
+    API_END
 }
 
 #define STR_BINARY(name)                                                                              \

@@ -453,9 +453,95 @@ int Circuit::run_host_parts(const uint64_t* const* parts, const uint32_t* counts
     return eng_->cluster_check();
 }
 
+static int grow(void** ptr, size_t* cap, size_t bytes) {
+    if (*cap >= bytes) return 0;
+    if (*ptr) HIP_TRY(hipFree(*ptr));
+    *ptr = nullptr; *cap = 0;
+    HIP_TRY(hipMalloc(ptr, bytes));
+    *cap = bytes;
+    return 0;
+}
+
+// ---- many instances of a plan in one pass ----
+int Circuit::batch_prepare(uint32_t M) {
+    if (!eng_) return fail("offline plan: no engine bound (there is no CPU execution path)");
+    if (world_ != 1) return fail("run_batch needs a plan finalised for world = 1 (instances shard over ranks, not levels)");
+    if (eng_->use()) return 1;
+    const size_t big = (size_t)p_.k * p_.N + 1;
+    size_t max_jobs = 1;
+    for (auto& lv : levels_) max_jobs = std::max(max_jobs, lv.jobs.size());
+    if ((uint64_t)pool_slots_ * M > 0x7FFFFFFFull || (uint64_t)max_jobs * M > 0x7FFFFFFFull) return fail("run_batch: too many instances");
+    // the streams of an earlier pass may still read these buffers while they are being replaced
+    if (bpool_cap_ < (size_t)pool_slots_ * M * big * 8 || bstage_cap_ < max_jobs * M * big * 8 || blut_cap_ < max_jobs * M * 4)
+        if (eng_->sync_all_streams()) return 1;
+    if (grow((void**)&d_bpool_, &bpool_cap_, (size_t)std::max<uint32_t>(pool_slots_, 1) * M * big * 8)) return 1;
+    if (grow((void**)&d_bstage_, &bstage_cap_, max_jobs * M * big * 8)) return 1;
+    if (grow((void**)&d_blut_, &blut_cap_, max_jobs * M * 4)) return 1;
+    return 0;
+}
+
+// input slots [first, first + count) of every instance <- d_src row (s * in_slot + i * in_inst); in_inst = 0 replicates
+int Circuit::batch_load(const uint64_t* d_src, uint32_t first, uint32_t count, uint32_t M, uint32_t in_slot, uint32_t in_inst) {
+    if (first + count > n_inputs_) return fail("run_batch: more input LWEs than the plan has inputs");
+    const size_t big = (size_t)p_.k * p_.N + 1;
+    return eng_->restride_dev(d_src, d_bpool_ + (size_t)first * M * big, count, M, in_slot, in_inst, M, 1);
+}
+
+int Circuit::batch_execute(uint64_t* d_outputs, uint32_t M) {
+    const size_t big = (size_t)p_.k * p_.N + 1;
+    const unsigned char* m = reinterpret_cast<const unsigned char*>(d_meta_);
+    for (const Level& lv : levels_) {
+        const uint32_t J = (uint32_t)lv.jobs.size();
+        if (!J) continue;
+        if (eng_->lincomb_batch_dev(d_bpool_, reinterpret_cast<const uint32_t*>(m + lv.meta_off), reinterpret_cast<const uint32_t*>(m + lv.meta_src),
+                                    reinterpret_cast<const int32_t*>(m + lv.meta_coeff), reinterpret_cast<const uint64_t*>(m + lv.meta_cst),
+                                    d_bstage_, J, M, M, 1, M, 1, reinterpret_cast<const uint32_t*>(m + lv.meta_lut), d_blut_))
+            return 1;
+        // rows (job j, instance i) -> pool rows (local_base + j, i): one contiguous batch (world 1: every job is local)
+        if (eng_->ks_pbs_dev(d_bstage_, d_blut_, d_bpool_ + (size_t)lv.local_base * M * big, J * M)) return 1;
+    }
+    return eng_->lincomb_batch_dev(d_bpool_, reinterpret_cast<const uint32_t*>(m + out_.meta_off), reinterpret_cast<const uint32_t*>(m + out_.meta_src),
+                                   reinterpret_cast<const int32_t*>(m + out_.meta_coeff), reinterpret_cast<const uint64_t*>(m + out_.meta_cst),
+                                   d_outputs, n_outputs(), M, M, 1, 1, n_outputs(), nullptr, nullptr);
+}
+
+int Circuit::run_batch_dev(const uint64_t* d_inputs, uint64_t* d_outputs, uint32_t instances) {
+    if (instances == 0) return 0;
+    if (batch_prepare(instances)) return 1;
+    if (batch_load(d_inputs, 0, n_inputs_, instances, 1, n_inputs_)) return 1;     // [instance][n_inputs] -> [slot][instance]
+    return batch_execute(d_outputs, instances);
+}
+
+// Host arrays: `rows` = [instances][row_count] ciphertexts (the first row_count inputs of every instance), `shared` =
+// [n_inputs - row_count] ciphertexts every instance reads (one encrypted pattern against many strings), or null.
+int Circuit::run_batch_host(const uint64_t* rows, uint32_t row_count, const uint64_t* shared, uint64_t* outputs, uint32_t instances) {
+    if (instances == 0) return 0;
+    if (row_count > n_inputs_ || (row_count < n_inputs_ && !shared)) return fail("run_batch: fewer input LWEs than the plan has inputs");
+    if (batch_prepare(instances)) return 1;
+    const size_t big = (size_t)p_.k * p_.N + 1;
+    const uint32_t n_shared = n_inputs_ - row_count;
+    const size_t rows_words = (size_t)row_count * instances * big, shared_words = (size_t)n_shared * big,
+                 out_words = (size_t)n_outputs() * instances * big;
+    if (bio_cap_ < (rows_words + shared_words + out_words) * 8 && eng_->sync_all_streams()) return 1;
+    if (grow((void**)&d_bio_, &bio_cap_, (rows_words + shared_words + out_words) * 8)) return 1;
+    uint64_t *d_rows = d_bio_, *d_shared = d_bio_ + rows_words, *d_out = d_shared + shared_words;
+    if (rows_words) HIP_TRY(hipMemcpyAsync(d_rows, rows, rows_words * 8, hipMemcpyHostToDevice, eng_->stream));
+    if (shared_words) HIP_TRY(hipMemcpyAsync(d_shared, shared, shared_words * 8, hipMemcpyHostToDevice, eng_->stream));
+    if (batch_load(d_rows, 0, row_count, instances, 1, row_count)) return 1;
+    if (n_shared && batch_load(d_shared, row_count, n_shared, instances, 1, 0)) return 1;
+    if (batch_execute(d_out, instances)) return 1;
+    HIP_TRY(hipMemcpyAsync(outputs, d_out, out_words * 8, hipMemcpyDeviceToHost, eng_->stream));
+    HIP_TRY(hipStreamSynchronize(eng_->stream));
+    return eng_->cluster_check();
+}
+
 Circuit::~Circuit() {
     if (!eng_) return;
     (void)hipSetDevice(eng_->device);
+    if (d_bpool_) (void)hipFree(d_bpool_);
+    if (d_bstage_) (void)hipFree(d_bstage_);
+    if (d_bio_) (void)hipFree(d_bio_);
+    if (d_blut_) (void)hipFree(d_blut_);
     if (d_meta_) (void)hipFree(d_meta_);
     if (d_stage_) (void)hipFree(d_stage_);
     if (d_own_pool_) (void)hipFree(d_own_pool_);

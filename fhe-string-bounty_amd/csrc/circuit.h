@@ -161,6 +161,15 @@ public:
     int gather_outputs(const uint64_t* d_pool, uint64_t* d_out);
     int run_host(const uint64_t* inputs, uint64_t* outputs);
     int run_host_parts(const uint64_t* const* parts, const uint32_t* counts, uint32_t n_parts, uint64_t* outputs);     // single GPU, host buffers
+    // `instances` independent copies of the plan (finalised for world 1) in one pass: level l of all instances is ONE
+    // gather + keyswitch + blind-rotation batch of instances x jobs(l) ciphertexts -- the reference's throughput shape
+    // (many independent inputs per call, benches/core_crypto/pbs_bench.rs:430-549; rayon over the blocks of an integer,
+    // integer/server_key/radix_parallel/comparison.rs:22-28) for whole operations.  inputs [instance][n_inputs],
+    // outputs [instance][n_outputs] ciphertexts; device pointers, ordered on the engine's stream.
+    int run_batch_dev(const uint64_t* d_inputs, uint64_t* d_outputs, uint32_t instances);
+    // host arrays: rows [instances][row_count] + `shared` (the remaining inputs, read by every instance; may be null when
+    // row_count == n_inputs)
+    int run_batch_host(const uint64_t* rows, uint32_t row_count, const uint64_t* shared, uint64_t* outputs, uint32_t instances);
     ~Circuit();
     Engine* engine() const { return eng_; }   // nullptr: offline plan
 
@@ -168,6 +177,9 @@ private:
     void set_error(std::string e) { if (error_.empty()) error_ = std::move(e); }   // the first error is the cause
     void flatten(uint32_t node, int64_t mult, std::map<uint32_t, int64_t>& acc, int64_t& cst) const;
     void build_csr(Level& lv, const std::vector<uint32_t>& lin_nodes);
+    int batch_prepare(uint32_t instances);
+    int batch_load(const uint64_t* d_src, uint32_t first, uint32_t count, uint32_t instances, uint32_t in_slot, uint32_t in_inst);
+    int batch_execute(uint64_t* d_outputs, uint32_t instances);
 
     fhe_params_t p_;
     Engine* eng_;
@@ -188,6 +200,11 @@ private:
     size_t stage_cap_ = 0;
     uint64_t* d_own_pool_ = nullptr;
     uint64_t* d_own_out_ = nullptr;
+    // batch execution (grown on demand): slot-major pool [slot][instance], one level's gathered rows, their table ids,
+    // staging of host inputs / outputs
+    uint64_t *d_bpool_ = nullptr, *d_bstage_ = nullptr, *d_bio_ = nullptr;
+    uint32_t* d_blut_ = nullptr;
+    size_t bpool_cap_ = 0, bstage_cap_ = 0, bio_cap_ = 0, blut_cap_ = 0;
 };
 
 }  // namespace fhe

@@ -145,6 +145,12 @@ struct Engine {
     int pbs_ks_host(const uint64_t* in_small, const uint32_t* lut_idx, uint64_t* out_small, uint32_t count);
     int lincomb_dev(const uint64_t* d_pool, const uint32_t* d_off, const uint32_t* d_src,
                     const int32_t* d_coeff, const uint64_t* d_cst, uint64_t* d_out, uint32_t jobs);
+    // `instances` copies of a plan level at once (lincomb_batch_kernel); strides in ciphertext rows
+    int lincomb_batch_dev(const uint64_t* d_pool, const uint32_t* d_off, const uint32_t* d_src, const int32_t* d_coeff,
+                          const uint64_t* d_cst, uint64_t* d_out, uint32_t jobs, uint32_t instances, uint32_t src_slot, uint32_t src_inst,
+                          uint32_t out_job, uint32_t out_inst, const uint32_t* d_lut_in, uint32_t* d_lut_out);
+    int restride_dev(const uint64_t* d_in, uint64_t* d_out, uint32_t slots, uint32_t instances, uint32_t in_slot, uint32_t in_inst,
+                     uint32_t out_slot, uint32_t out_inst);
     int lincomb_host(const uint64_t* pool, uint32_t pool_count, const uint32_t* off, const uint32_t* src,
                      const int32_t* coeff, const uint64_t* cst, uint64_t* out, uint32_t jobs);
     int last_kernel_ms(float ms[2]);

@@ -1127,6 +1127,27 @@ int Engine::lincomb_dev(const uint64_t* d_pool_, const uint32_t* d_off, const ui
     return 0;
 }
 
+int Engine::lincomb_batch_dev(const uint64_t* d_pool_, const uint32_t* d_off, const uint32_t* d_src, const int32_t* d_coeff,
+                              const uint64_t* d_cst, uint64_t* d_o, uint32_t jobs, uint32_t instances, uint32_t src_slot, uint32_t src_inst,
+                              uint32_t out_job, uint32_t out_inst, const uint32_t* d_lut_in, uint32_t* d_lut_out) {
+    if (jobs == 0 || instances == 0) return 0;
+    if ((uint64_t)jobs * instances > 0x7FFFFFFFull) return fail("lincomb batch: jobs * instances exceeds the grid limit");
+    LincombBatchArgs b{{d_pool_, d_off, d_src, d_coeff, d_cst, d_o, p.k * p.N + 1, jobs}, instances, src_slot, src_inst, out_job, out_inst,
+                       d_lut_in, d_lut_out};
+    hipLaunchKernelGGL(lincomb_batch_kernel, dim3(jobs * instances), dim3(256), 0, stream, b);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int Engine::restride_dev(const uint64_t* d_i, uint64_t* d_o, uint32_t slots, uint32_t instances, uint32_t in_slot, uint32_t in_inst,
+                         uint32_t out_slot, uint32_t out_inst) {
+    if (slots == 0 || instances == 0) return 0;
+    hipLaunchKernelGGL(lwe_restride_kernel, dim3(slots * instances), dim3(256), 0, stream, d_i, d_o, p.k * p.N + 1, instances, in_slot, in_inst,
+                       out_slot, out_inst);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int Engine::lincomb_host(const uint64_t* pool, uint32_t pool_count, const uint32_t* off,
                          const uint32_t* src, const int32_t* coeff, const uint64_t* cst,
                          uint64_t* out, uint32_t jobs) {

@@ -175,4 +175,42 @@ __global__ void __launch_bounds__(256) lincomb_kernel(LincombArgs a) {
     }
 }
 
+// The same gather for `instances` independent copies of a plan at once (fhe_plan_run_batch): workgroup (j, i) combines
+// the sources of job j in instance i's pool.  Ciphertext (slot s, instance i) sits at (s * src_slot + i * src_inst) rows,
+// the result of (job j, instance i) at (j * out_job + i * out_inst) rows -- slot-major pools [slot][instance] make the
+// outputs of one level, ordered (job, instance), ONE contiguous keyswitch / blind-rotation batch; the strides also
+// describe the caller's instance-major input and output arrays.  lut_out (optional): the job's table id, per output row.
+struct LincombBatchArgs {
+    LincombArgs base;
+    uint32_t instances;
+    uint32_t src_slot, src_inst, out_job, out_inst;
+    const uint32_t* lut_in;    // [jobs] or nullptr
+    uint32_t* lut_out;         // [jobs * instances] in output row order
+};
+
+__global__ void __launch_bounds__(256) lincomb_batch_kernel(LincombBatchArgs b) {
+    const LincombArgs& a = b.base;
+    const uint32_t j = blockIdx.x / b.instances, i = blockIdx.x % b.instances;
+    const uint32_t t0 = a.off[j], t1 = a.off[j + 1];
+    const size_t row = (size_t)j * b.out_job + (size_t)i * b.out_inst;
+    for (uint32_t e = threadIdx.x; e < a.size; e += blockDim.x) {
+        uint64_t v = 0;
+        for (uint32_t t = t0; t < t1; t++)
+            v += a.pool[((size_t)a.src[t] * b.src_slot + (size_t)i * b.src_inst) * a.size + e] * (uint64_t)(int64_t)a.coeff[t];
+        if (e == a.size - 1) v += a.cst[j];
+        a.out[row * a.size + e] = v;
+    }
+    if (b.lut_out && threadIdx.x == 0) b.lut_out[row] = b.lut_in[j];
+}
+
+// out[(s * out_slot + i * out_inst)] = in[(s * in_slot + i * in_inst)]: instance-major caller arrays <-> slot-major pools
+__global__ void __launch_bounds__(256) lwe_restride_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t size,
+                                                           uint32_t instances, uint32_t in_slot, uint32_t in_inst, uint32_t out_slot,
+                                                           uint32_t out_inst) {
+    const uint32_t s = blockIdx.x / instances, i = blockIdx.x % instances;
+    const uint64_t* src = in + ((size_t)s * in_slot + (size_t)i * in_inst) * size;
+    uint64_t* dst = out + ((size_t)s * out_slot + (size_t)i * out_inst) * size;
+    for (uint32_t e = threadIdx.x; e < size; e += blockDim.x) dst[e] = src[e];
+}
+
 }  // namespace fhe

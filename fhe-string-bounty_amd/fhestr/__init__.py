@@ -146,7 +146,7 @@ EXPORTS = [
     "fhe_plan_create", "fhe_plan_destroy", "fhe_plan_input", "fhe_plan_lut", "fhe_plan_lin", "fhe_plan_pbs",
     "fhe_plan_output", "fhe_plan_finalize", "fhe_plan_info", "fhe_plan_level_info", "fhe_plan_export_level",
     "fhe_plan_run", "fhe_plan_run_level_rank_dev", "fhe_plan_gather_outputs_dev", "fhe_str_plan_create",
-    "fhe_plan_level_rank_info", "fhe_plan_noise_info", "fhe_noise_model", "fhe_noise_model_is_calibrated", "fhe_params_supported", "fhe_plan_set_noise_budget",
+    "fhe_plan_level_rank_info", "fhe_plan_noise_info", "fhe_noise_model", "fhe_noise_model_is_calibrated", "fhe_params_supported", "fhe_plan_run_batch", "fhe_plan_run_batch_dev", "fhe_str_op_many", "fhe_plan_set_noise_budget",
     "fhe_host_alloc", "fhe_host_free",
     "fhe_plan_pbs_signed", "fhe_plan_pbs_full_box", "fhe_plan_set_owner_hint",
     "fhe_str_to_upper", "fhe_str_to_lower", "fhe_plan_create_offline", "fhe_str_plan_create_offline",
@@ -242,6 +242,9 @@ def lib() -> C.CDLL:
     sig("fhe_plan_level_info", vp, u32, C.POINTER(u32))
     sig("fhe_plan_export_level", vp, u32, vp, vp, vp, vp, vp)
     sig("fhe_plan_run", vp, vp, vp)
+    sig("fhe_plan_run_batch", vp, u32, vp, vp)
+    sig("fhe_plan_run_batch_dev", vp, u32, vp, vp)
+    sig("fhe_str_op_many", vp, C.c_char_p, vp, u32, u32, vp, u32, vp, u32, vp, C.POINTER(u32))
     sig("fhe_plan_run_level_rank_dev", vp, vp, u32, u32)
     sig("fhe_plan_level_rank_info", vp, u32, u32, C.POINTER(u32))
     sig("fhe_plan_noise_info", vp, C.POINTER(C.c_double))
@@ -795,6 +798,22 @@ class Plan:
         _check(lib().fhe_plan_run(self._h, _ptr(inputs) if inputs.size else None, _ptr(out)))
         return out
 
+    def run_batch(self, inputs) -> np.ndarray:
+        """Many independent instances of the plan in one pass (fhe_plan_run_batch): inputs (instances, n_inputs, kN+1)
+        -> outputs (instances, n_outputs, kN+1).  Level l of all instances is one launch."""
+        p = self.params
+        info = self.info()
+        inputs = _u64(inputs)
+        if inputs.ndim != 3 or inputs.shape[1:] != (info["n_inputs"], p.big_size):
+            raise FheError(f"run_batch expects (instances, {info['n_inputs']}, {p.big_size}) ciphertext words, got {inputs.shape}")
+        out = np.zeros((inputs.shape[0], info["n_outputs"], p.big_size), dtype=np.uint64)
+        _check(lib().fhe_plan_run_batch(self._h, inputs.shape[0], _ptr(inputs) if inputs.size else None, _ptr(out)))
+        return out
+
+    def run_batch_dev(self, d_inputs: int, d_outputs: int, instances: int):
+        """The same on device arrays (raw pointers), ordered on the engine's stream; no host synchronisation."""
+        _check(lib().fhe_plan_run_batch_dev(self._h, instances, C.c_void_p(d_inputs), C.c_void_p(d_outputs)))
+
     def run_level_rank_dev(self, d_pool: int, level: int, rank: int):
         _check(lib().fhe_plan_run_level_rank_dev(self._h, C.c_void_p(d_pool), level, rank))
 
@@ -863,6 +882,33 @@ class FheStringOps:
             b, b_cap = self._cap(b)
             _check(getattr(lib(), f"fhe_str_{op}")(self.engine.handle, _ptr(a), a_cap, _ptr(b), b_cap, _ptr(out)))
         return out
+
+    def op_many(self, op, rows, b=None):
+        """`op` on every row against ONE second operand in a single pass (fhe_str_op_many): rows (count, cap*blocks, kN+1);
+        b: an encrypted (zero padded) string, clear bytes, or None for unary operations.  Returns (count, n_outputs, kN+1)."""
+        big = self.engine.params.big_size
+        rows = _u64(rows)
+        if rows.ndim != 3 or rows.shape[2] != big:
+            raise FheError(f"op_many expects rows of shape (count, cap*blocks, {big})")
+        count, a_cap = rows.shape[0], rows.shape[1] // self.bpc
+        clear = b if isinstance(b, (bytes, bytearray)) else None
+        enc = None if (b is None or clear is not None) else self._cap(b)
+        name = op + ("_clear" if clear is not None else "")
+        buf = (C.c_uint8 * max(1, len(clear)))(*clear) if clear is not None else None
+        args = (self.engine.handle, name.encode(), _ptr(rows), a_cap, count, _ptr(enc[0]) if enc else None, enc[1] if enc else 0,
+                buf, len(clear) if clear is not None else 0)
+        n_out = C.c_uint32(0)
+        _check(lib().fhe_str_op_many(*args, None, C.byref(n_out)))          # outputs per row (builds and caches the plan)
+        out = self._alloc((count, n_out.value, big))
+        _check(lib().fhe_str_op_many(*args, _ptr(out), C.byref(n_out)))
+        return out
+
+    def eq_many(self, rows, b): return self.op_many("eq", rows, b)[:, 0]
+    def ne_many(self, rows, b): return self.op_many("ne", rows, b)[:, 0]
+    def contains_many(self, rows, b): return self.op_many("contains", rows, b)[:, 0]
+    def starts_with_many(self, rows, b): return self.op_many("starts_with", rows, b)[:, 0]
+    def ends_with_many(self, rows, b): return self.op_many("ends_with", rows, b)[:, 0]
+    def find_many(self, rows, b): return self.op_many("find", rows, b)
 
     def eq(self, a, b): return self._binary("eq", a, b)[0]
     def ne(self, a, b): return self._binary("ne", a, b)[0]

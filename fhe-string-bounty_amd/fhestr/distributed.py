@@ -38,6 +38,41 @@ class ShardedPlanRunner:
         return b.gather_outputs(pool, self.info["n_outputs"])
 
 
+def instance_slice(instances: int, rank: int, world: int):
+    """Contiguous share of `instances` independent plan instances rank `rank` runs (the first ranks take one more)."""
+    base, extra = divmod(instances, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def run_instances_sharded(run_batch, inputs, rank: int, world: int, group=None, gather=True):
+    """Many instances of ONE plan over several GPUs: instances are independent, so every rank runs its slice with
+    fhe_plan_run_batch (`run_batch(inputs[lo:hi]) -> outputs`; a plan finalised for world 1, keys replicated) and NO
+    data-path collective is needed -- this is the form in which 8 GPUs help FheString::eq (DESIGN.md section 5).  With
+    gather=True the outputs are then all-gathered so that every rank returns all of them (control plane: a few ciphertexts
+    per instance); gather=False returns the rank's own slice."""
+    inputs = np.asarray(inputs, dtype=np.uint64)
+    n = inputs.shape[0]
+    lo, hi = instance_slice(n, rank, world)
+    mine = run_batch(inputs[lo:hi]) if hi > lo else None
+    if world == 1 or not gather:
+        return mine
+    import torch
+    import torch.distributed as dist
+    share = max(instance_slice(n, r, world)[1] - instance_slice(n, r, world)[0] for r in range(world))
+    shape = None if mine is None else mine.shape[1:]
+    shapes = [None] * world
+    dist.all_gather_object(shapes, shape, group=group)
+    shape = next(s for s in shapes if s is not None)
+    padded = np.zeros((share,) + tuple(shape), dtype=np.uint64)
+    if mine is not None:
+        padded[: hi - lo] = mine
+    everyone = torch.empty((world * share,) + tuple(shape), dtype=torch.int64)
+    dist.all_gather_into_tensor(everyone, torch.from_numpy(padded.view(np.int64)), group=group)
+    everyone = everyone.numpy().view(np.uint64).reshape((world, share) + tuple(shape))
+    return np.concatenate([everyone[r, : instance_slice(n, r, world)[1] - instance_slice(n, r, world)[0]] for r in range(world)])
+
+
 class GpuBackend:
     """Product backend: pool in HBM (torch tensor), HIP kernels via the C ABI, RCCL all-gather.
     staged=True gathers through host memory instead (gloo group: rehearsing several ranks on one GPU)."""

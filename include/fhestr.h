@@ -253,6 +253,17 @@ int fhe_plan_lut_count(const fhe_plan *plan, uint32_t *count);
 int fhe_plan_export_lut(const fhe_plan *plan, uint32_t lut, uint64_t *accumulator);
 /* single GPU, host buffers: inputs n_inputs x (kN+1), outputs n_outputs x (kN+1) */
 int fhe_plan_run(fhe_plan *plan, const uint64_t *inputs, uint64_t *outputs);
+/* `instances` independent copies of the plan (finalised for world 1) in ONE pass: level l of all instances is one gather +
+ * one keyswitch + one blind-rotation launch over instances x jobs(l) ciphertexts.  This is the reference's throughput shape
+ * -- many independent inputs per call (benches/core_crypto/pbs_bench.rs:430-549; rayon over the blocks of an integer,
+ * integer/server_key/radix_parallel/comparison.rs:22-28) -- for whole operations: a single FheString::eq pays four dependent
+ * single-PBS latencies on a nearly idle GPU (12.8 ms), 32 of them share those four and run at the engine's batch rate.
+ * inputs: [instances][n_inputs] ciphertexts, outputs: [instances][n_outputs] (host arrays; _dev: device arrays, ordered on
+ * the engine's stream, no host synchronisation).  Every instance's outputs are those of fhe_plan_run on its inputs (the same
+ * gathers and tables; batches beyond one LWE per CU run the two-LWEs-per-CU kernel: decrypt-identical, not bit-identical).
+ * With several GPUs the instances shard over the ranks -- no collective at all. */
+int fhe_plan_run_batch(fhe_plan *plan, uint32_t instances, const uint64_t *inputs, uint64_t *outputs);
+int fhe_plan_run_batch_dev(fhe_plan *plan, uint32_t instances, const uint64_t *d_inputs, uint64_t *d_outputs);
 /* multi-GPU building blocks (device pool of pool_slots big LWEs; inputs live in slots [0, n_inputs) on
  * every rank): run `rank`'s jobs of one level; gather the outputs once the last level is through. */
 int fhe_plan_run_level_rank_dev(fhe_plan *plan, uint64_t *d_pool, uint32_t level, uint32_t rank);
@@ -336,6 +347,13 @@ int fhe_str_replace(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const ui
                     uint32_t pat_cap, uint64_t *out);
 int fhe_str_replace_clear(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, const uint8_t *from,
                           const uint8_t *to, uint32_t pat_len, uint64_t *out);
+/* Many strings against ONE second operand in one pass (fhe_plan_run_batch on the operation's cached plan): `op` is an
+ * operation name of fhe_str_plan_create ("eq", "ne", "contains", "find", "starts_with", "to_lower", ...; "<op>_clear" with
+ * a clear pattern), rows = [count][a_cap * blocks] ciphertexts, b = the shared encrypted operand ([b_cap * blocks]
+ * ciphertexts, b_cap = 0 and NULL for unary operations and clear patterns), out = [count][n_outputs] ciphertexts,
+ * *n_outputs (optional) = outputs per row; with out == NULL the call only builds the plan and returns that number.  One pattern against 32 rows: FheString::eq 12.8 ms alone, under 5 ms per row. */
+int fhe_str_op_many(fhe_engine *eng, const char *op, const uint64_t *rows, uint32_t a_cap, uint32_t count, const uint64_t *b,
+                    uint32_t b_cap, const uint8_t *clear, uint32_t clear_len, uint64_t *out, uint32_t *n_outputs);
 /* len: ceil(log_msg_mod(cap+1)) little-endian digits; is_empty: one 0/1 block */
 int fhe_str_len(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);
 int fhe_str_is_empty(fhe_engine *eng, const uint64_t *a, uint32_t a_cap, uint64_t *out);

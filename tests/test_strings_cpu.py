@@ -631,3 +631,56 @@ def test_find_on_one_bit_blocks(s, pat):
         assert out[0] == int(idx >= 0) and (idx < 0 or got == idx), (op, out, idx)
     with pytest.raises(fhestr.FheError, match="overflows"):
         fhestr.Plan.string_op(None, "find", 6, 2, None, 1, params=P)
+
+
+# ---- many instances of one plan, sharded over ranks (fhestr.distributed.run_instances_sharded) ----
+BATCH_ROWS = [b"hello", b"hellp", b"", b"hell", b"hello!!", b"HELLO", b"hello"]      # 7 instances: uneven over 2 and 4 ranks
+
+
+def _instances_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fhestr
+    from fhestr.distributed import run_instances_sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ks = keyset(O.TOY_K1)
+    P = to_fhestr_params(O.TOY_K1)
+    plan = fhestr.Plan.string_op(None, "eq", 8, 8, None, 1, params=P)      # world 1: instances shard, levels do not
+    pat = _enc(ks, b"hello", 8)
+    inputs = np.stack([np.concatenate([_enc(ks, r, 8), pat]) for r in BATCH_ROWS])
+    calls = []
+
+    def run_batch(x):       # the checker's stand-in for fhe_plan_run_batch: the oracle, one instance at a time
+        calls.append(x.shape[0])
+        return np.stack([run_with_oracle(plan, inst, ks.sk) for inst in x])
+
+    out = run_instances_sharded(run_batch, inputs, rank, world)
+    ret[rank] = (ks.ck.decrypt_many(out[:, 0]).tolist(), calls)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_instances_sharded_over_ranks_gloo(world):
+    """Many strings against one pattern over several ranks: every rank runs a contiguous slice of the instances (no
+    data-path collective), the outputs are gathered; all ranks hold all results.  7 instances over 2 and 4 ranks."""
+    import torch.multiprocessing as mp
+    from fhestr.distributed import instance_slice
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_instances_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    want = [int(r == b"hello") for r in BATCH_ROWS]
+    slices = [instance_slice(len(BATCH_ROWS), r, world) for r in range(world)]
+    assert slices[0][0] == 0 and slices[-1][1] == len(BATCH_ROWS) and all(a[1] == b[0] for a, b in zip(slices, slices[1:]))
+    for r in range(world):
+        got, calls = ret[r]
+        assert got == want, f"rank {r}"
+        assert calls == [slices[r][1] - slices[r][0]]
