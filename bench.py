@@ -198,6 +198,10 @@ def bench_strings(fhestr, eng, ck, P, rank, world, local_rank, reps=3, staged=Fa
         "to_lower_1024": ("to_lower", 1024, 0, None, enc(text, 1024), chars(text.lower(), 1024), 2),
         "replace_clear_4_in_1024": ("replace_clear", 1024, 0, b"the THAT", enc(text, 1024),
                                     chars(text.replace(b"the ", b"THAT"), 1024), 2),
+        # the same with an ENCRYPTED 4-character pattern and replacement: the occurrences need a scan over the offsets
+        # (fhe_string.cpp: occurrences_scan -- blocked, 2 B + n / B lookup levels instead of n / 2)
+        "replace_enc_4_in_1024": ("replace", 1024, 8, None, np.concatenate([enc(text, 1024), enc(b"the ", 4), enc(b"THAT", 4)]),
+                                  chars(text.replace(b"the ", b"THAT"), 1024), 2),
     }
     out = {}
     dev = torch.device("cuda", local_rank)
@@ -526,13 +530,16 @@ def bench_p44(fhestr, local_rank):
             return locked[key]
 
         locked_out(es.shape)
+        e_from, e_to = ck.encrypt(fhestr.string_to_blocks(P, b"the ", 4)), ck.encrypt(fhestr.string_to_blocks(P, b"THAT", 4))
         ops = fhestr.FheStringOps(eng, out_alloc=locked_out)
         dec = lambda ct: fhestr.blocks_to_string(P, ck.decrypt(ct))
         strings = {}
         for name, fn, want, plan_args in (
                 ("to_lower_1024", lambda: ops.to_lower(es), s.lower(), ("to_lower", 1024, 0, None)),
                 ("replace_clear_4_in_1024", lambda: ops.replace(es, b"the ", b"THAT"), s.replace(b"the ", b"THAT"),
-                 ("replace_clear", 1024, 0, b"the THAT"))):
+                 ("replace_clear", 1024, 0, b"the THAT")),
+                # encrypted pattern and replacement: the blocked occurrence scan, blocks of 64 offsets on this parameter set
+                ("replace_enc_4_in_1024", lambda: ops.replace(es, e_from, e_to), s.replace(b"the ", b"THAT"), ("replace", 1024, 8, None))):
             t0 = time.perf_counter()
             res = fn()
             ms = (time.perf_counter() - t0) * 1e3

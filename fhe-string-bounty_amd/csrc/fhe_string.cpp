@@ -55,6 +55,7 @@ public:
     };
     // ---- noise: split a sum into pieces one lookup may take (value bound max_terms, noise budget) ----
     double budget() const { return c.noise_budget() > 0 ? c.noise_budget() : 1e300; }
+    bool p_large() const { return c.params().N >= 16384; }      // a lookup level costs what its lookups cost, not one PBS latency
     // A whole character as ONE lookup input, hi * M + lo: needs two blocks per char whose 8 bits fit the message +
     // carry space (PARAM_MESSAGE_4_CARRY_4: 4-bit blocks, 256 plaintexts) and 1 + M^2 nominal variances within the
     // noise budget -- "one PBS per encrypted character".  Per-character predicates and case conversion then cost 1
@@ -889,9 +890,118 @@ public:
         std::vector<uint32_t> sel;     // [offset]
         std::vector<uint32_t> cover;   // [char] 0/1: inside a selected occurrence
     };
+    // The leftmost non-overlapping occurrences as a BLOCKED SCAN (round 4).  The recurrence below is a chain over the offsets,
+    // one lookup level per two of them (n / 2 levels: 0.33 s for 256 characters on PARAM_MESSAGE_2_CARRY_2, each level a single-
+    // PBS latency).  Its state is small: r[o] = how many more characters the occurrence selected before o still covers, in
+    // [0, m).  One step is ONE lookup,   r[o+1] = (r[o] == 0) ? g[o] : r[o] - 1   on   x = r[o] + m g[o],
+    // with g[o] = match[o] * (L - 1) (L = the pattern's length: m, or the hidden number of non-null characters of a padded
+    // encrypted pattern -- then g costs one lookup per offset, off the chain).  Blocks of B offsets run their chains for every
+    // possible incoming state at once (m hypotheses, constants at the block's start), the true state then hops from block to
+    // block through the blocks' state maps (m lookups per hop: select F_b[R_b] by the encrypted R_b), and every block re-runs
+    // its chain from its true incoming state.  Depth 2 B + n / B instead of n / 2 -- B + n / B with two offsets per chain step
+    // (1024 characters, 4-character pattern: 66 levels instead of 511) --, about (m + 1) n chain lookups instead of n.  sel[o] = [r[o] == 0 and match[o]] and cover[o] = [r[o] > 0 or
+    // match[o]] are read off x' = r[o] + m match[o] afterwards.  Needs m^2 <= T (hidden length) or 2 m <= T; the recurrence
+    // stays for longer patterns, short strings and where the noise does not fit.
+    bool blocked_scan = true;
+    bool occurrences_scan(const std::vector<uint32_t>& match, uint32_t m, uint32_t n_chars, const std::vector<uint32_t>* nzf, Occurrences& oc) {
+        const uint32_t n = (uint32_t)match.size();
+        if (!blocked_scan || m < 2 || n < 48) return false;
+        const bool hidden = nzf != nullptr;
+        if (hidden ? (uint64_t)m * m > T : 2ull * m > T) return false;
+        for (uint32_t o = 0; o < n; o++) if (is_trivial(match[o])) return false;      // (plans with clear operands: keep the recurrence)
+        const uint32_t mm = m;
+        std::vector<uint32_t> g(n);
+        if (hidden) {
+            std::vector<Term> t;
+            double nu = 0;
+            for (uint32_t j = 1; j < m; j++) { t.push_back({(*nzf)[j], 1}); nu += c.node((*nzf)[j]).noise; }
+            const uint32_t lm1 = c.lin(t, 0, m - 1);          // L - 1 (padding sits at the end; an empty pattern matches nowhere)
+            const uint32_t gl = c.lut_fn([mm](uint64_t x) { return (x & 1) ? std::min<uint64_t>(x >> 1, mm - 1) : (uint64_t)0; });
+            for (uint32_t o = 0; o < n; o++) {
+                if (c.node(match[o]).noise + 4 * nu > budget()) return false;
+                Scope sc(c, owner_for(o, n));
+                g[o] = c.pbs(c.lin({{match[o], 1}, {lm1, 2}}), gl);
+            }
+            if (1.0 + (double)m * m * 1.0 + (double)m > budget()) return false;    // chain input: r (up to m outputs summed) + m g
+        } else {
+            g = match;
+            for (uint32_t o = 0; o < n; o++)
+                if ((double)m + (double)m * m * c.node(match[o]).noise > budget()) return false;
+        }
+        const uint32_t step = hidden ? c.lut_fn([mm](uint64_t x) { return x % mm == 0 ? x / mm : x % mm - 1; })
+                                     : c.lut_fn([mm](uint64_t x) { const uint64_t r = x % mm; return r == 0 ? (x / mm ? (uint64_t)mm - 1 : (uint64_t)0) : r - 1; });
+        const uint32_t n_ext = std::min(n_chars, n + m - 1);      // past the last offset an occurrence may still run
+        const uint32_t zero = c.trivial(0);
+        auto g_at = [&](uint32_t o) { return o < n ? g[o] : zero; };
+        // Two offsets per chain step where the box and the noise allow it: x = r + m g[o] + W g[o+1], W = m^2 (hidden length:
+        // g in [0, m)) or 2 m (known length: g is the match bit) -- known length m = 4 fills the 16 values of PARAM_MESSAGE_2_CARRY_2
+        // exactly.  The state between the two (needed for sel / cover on the true chains only) is one more lookup off the chain.
+        const uint32_t W = hidden ? m * m : 2 * m;
+        const bool pairs = (hidden ? (uint64_t)m * m * m : 4ull * m) <= T && (double)m + (double)m * m + (double)W * W <= budget();
+        auto one = [mm, hidden](uint64_t r, uint64_t gv) -> uint64_t { return r == 0 ? (hidden ? gv : (gv ? (uint64_t)mm - 1 : (uint64_t)0)) : r - 1; };
+        const uint32_t step2 = !pairs ? 0u : c.lut_fn([mm, W, one](uint64_t x) { return one(one(x % mm, (x % W) / mm), x / W); });
+        // state entering lo, lo + 1, ..., hi (hi - lo + 1 values; only the last one unless `all`) from the state `start` entering lo
+        auto chain = [&](uint32_t start, uint32_t lo, uint32_t hi, bool all) {
+            std::vector<uint32_t> r{start};
+            uint32_t cur = start;
+            for (uint32_t o = lo; o < hi;) {
+                if (pairs && o + 1 < hi) {
+                    if (all) r.push_back(c.pbs(c.lin({{cur, 1}, {g_at(o), (int32_t)mm}}), step));
+                    cur = c.pbs(c.lin({{cur, 1}, {g_at(o), (int32_t)mm}, {g_at(o + 1), (int32_t)W}}), step2);
+                    o += 2;
+                } else {
+                    cur = c.pbs(c.lin({{cur, 1}, {g_at(o), (int32_t)mm}}), step);
+                    o += 1;
+                }
+                if (all) r.push_back(cur);
+            }
+            if (!all) r.assign(1, cur);
+            return r;
+        };
+        uint32_t B = 1;
+        while ((pairs ? 1ull : 2ull) * B * B < n_ext) B++;        // minimises (2 B or B) + n / B
+        if (p_large()) B = std::max(B, std::min<uint32_t>(64, n_ext));      // N >= 16384: a level costs what its lookups cost, fewer hypotheses' worth of them
+        const uint32_t nb = (n_ext + B - 1) / B;
+        std::vector<uint32_t> r_true(n_ext + 1);
+        {
+            const std::vector<uint32_t> r0 = chain(zero, 0, std::min(B, n_ext), true);
+            std::copy(r0.begin(), r0.end(), r_true.begin());
+        }
+        uint32_t R = r_true[std::min(B, n_ext)];                  // true state entering block 1
+        for (uint32_t b = 1; b < nb; b++) {
+            const uint32_t lo = b * B, hi = std::min(n_ext, lo + B);
+            const std::vector<uint32_t> rt = chain(R, lo, hi, true);
+            std::copy(rt.begin(), rt.end(), r_true.begin() + lo);
+            if (b + 1 < nb) {                                      // the block's state map, then the hop to the next block
+                std::vector<Term> parts;
+                for (uint32_t sidx = 0; sidx < m; sidx++) {
+                    const uint32_t f = chain(c.trivial(sidx), lo, hi, false).back();
+                    const uint32_t pick = c.lut_fn([mm, sidx](uint64_t x) { return x % mm == sidx ? x / mm : (uint64_t)0; });
+                    parts.push_back({c.pbs(c.lin({{R, 1}, {f, (int32_t)mm}}), pick), 1});
+                }
+                R = c.lin(parts, 0, m - 1);                        // exactly one hypothesis is the true one
+            }
+        }
+        const uint32_t is_sel = c.lut_fn([mm](uint64_t x) { return (uint64_t)(x == mm); });
+        const uint32_t nzl = c.lut_fn([](uint64_t x) { return (uint64_t)(x != 0); });
+        oc.sel.resize(n);
+        oc.cover.assign(n_chars, zero);
+        for (uint32_t i = 0; i < n_ext; i++) {
+            Scope sc(c, owner_for(i, n_ext));
+            if (i < n) {
+                const uint32_t x = c.lin({{r_true[i], 1}, {match[i], (int32_t)mm}});
+                oc.sel[i] = i == 0 ? match[0] : c.pbs(x, is_sel);
+                oc.cover[i] = i == 0 ? match[0] : c.pbs(x, nzl);
+            } else {
+                oc.cover[i] = c.pbs(r_true[i], nzl);
+            }
+        }
+        return true;
+    }
     Occurrences occurrences(const std::vector<uint32_t>& match, uint32_t m, uint32_t n_chars, bool may_overlap,
                             const std::vector<uint32_t>* nzf) {
         Occurrences oc;
+        if (may_overlap && occurrences_scan(match, m, n_chars, nzf, oc)) return oc;
         std::map<std::pair<uint32_t, uint32_t>, uint32_t> running;   // (offset, j) -> sel[offset] AND nzf[j]
         auto run_bit = [&](uint32_t o, uint32_t j) {
             if (!nzf || j == 0) return oc.sel[o];

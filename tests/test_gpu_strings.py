@@ -121,6 +121,28 @@ def test_p22_replace_to_lower_strip_64_chars(p22):
     assert fhestr.blocks_to_string(P, _dec(p22, ops.strip(es))) == s.strip()
 
 
+@pytest.mark.parametrize("s,frm,to", [
+    ((b"ab" * 33)[:64], b"aba", b"XYZ"),                                        # self-overlapping, borders of length 1
+    ((b"ab" * 32)[:63] + b"b", b"abab", b"WXYZ"),                               # borders of length 2, broken tail
+    (b"a" * 64, b"aaa", b"123"),                                                # every offset matches
+    (b"x" * 20 + b"the " + b"y" * 17 + b"the the " + b"z" * 15, b"the ", b"THAT"),   # isolated and adjacent occurrences
+    (b"q" * 61 + b"abc", b"abc", b"XYZ"),                                       # only the last offset
+])
+def test_p22_replace_encrypted_pattern_64_chars_blocked_scan(p22, s, frm, to):
+    """replace with an ENCRYPTED pattern and replacement on PARAM_MESSAGE_2_CARRY_2, 64 characters: the
+    leftmost non-overlapping occurrences come from the blocked scan (fhe_string.cpp: occurrences_scan; two offsets per
+    chain step for these unpadded 3- and 4-character patterns), against bytes.replace; then the padded (hidden-length) form."""
+    import fhestr
+    ops = _ops(p22)
+    P = gpu_engine(p22).params
+    es = _enc(p22, s, 64)
+    want = s.replace(frm, to)
+    out = ops.replace(es, _enc(p22, frm, len(frm)), _enc(p22, to, len(to)))
+    assert fhestr.blocks_to_string(P, _dec(p22, out)) == want
+    padded = ops.replace(es, _enc(p22, frm, 4), _enc(p22, to, 4), out_cap=64)
+    assert fhestr.blocks_to_string(P, _dec(p22, padded)) == want
+
+
 def test_plan_matches_oracle_execution(toy_k1):
     """Same plan, same inputs: GPU executor vs the oracle stepping through the exported levels."""
     import fhestr

@@ -684,3 +684,63 @@ def test_instances_sharded_over_ranks_gloo(world):
         got, calls = ret[r]
         assert got == want, f"rank {r}"
         assert calls == [slices[r][1] - slices[r][0]]
+
+
+# ---- replace with an ENCRYPTED pattern at scale: the blocked occurrence scan (fhe_string.cpp: occurrences_scan) ----
+def _periodic(unit, n):
+    return (unit * (n // len(unit) + 1))[:n]
+
+
+SCAN_CASES = [
+    # (string, from, to): self-overlapping patterns are the point -- leftmost non-overlapping occurrences (bytes.replace)
+    (_periodic(b"a", 64), b"aa", b"XY"),                       # every offset matches; pairs
+    (_periodic(b"ab", 64), b"aba", b"XYZ"),                    # borders of length 1
+    (_periodic(b"ab", 63) + b"b", b"abab", b"WXYZ"),           # borders of length 2, a broken tail
+    (b"x" * 20 + b"abcd" + b"y" * 17 + b"abcdabcd" + b"z" * 15, b"abcd", b"1234"),   # isolated and adjacent occurrences
+    (b"q" * 64, b"abc", b"XYZ"),                               # no occurrence at all
+    (b"abc" + b"q" * 58 + b"abc", b"abc", b"XYZ"),             # first and last offset
+    (_periodic(b"aab", 50), b"aa", b"ZZ"),                     # shorter than the capacity: padded string
+]
+
+
+@pytest.mark.parametrize("s,frm,to", SCAN_CASES)
+def test_replace_encrypted_pattern_blocked_scan_in_place(toy_k1, s, frm, to):
+    """64-character strings, unpadded encrypted `from` / `to` of 2 .. 4 characters, rewritten in place: the occurrence
+    recurrence runs as a blocked scan (state = characters still covered, one lookup per step, blocks evaluated for every
+    incoming state, state maps composed block by block).  Oracle-executed plan == bytes.replace; far fewer levels than
+    the two-offsets-per-level recurrence."""
+    import fhestr
+    P = to_fhestr_params(O.TOY_K1)
+    m = len(frm)
+    plan = _plan("replace", 64, 2 * m)
+    info = plan.info()
+    assert info["n_levels"] < 64 // 2, info          # the recurrence alone would need (64 - m) / 2 levels
+    inputs = np.concatenate([_enc(toy_k1, s, 64), _enc(toy_k1, frm, m), _enc(toy_k1, to, m)])
+    got = toy_k1.ck.decrypt_many(run_with_oracle(plan, inputs, toy_k1.sk))
+    assert fhestr.blocks_to_string(P, got) == s.replace(frm, to)
+
+
+@pytest.mark.parametrize("s,frm,to", [(_periodic(b"ab", 56), b"aba", b"-"), (_periodic(b"a", 56), b"aa", b"XYZ"),
+                                      (b"x" * 20 + b"abcd" + b"y" * 20 + b"abcdabcd", b"abcd", b""),
+                                      (_periodic(b"ab", 56), b"", b"Q"), (_periodic(b"abc", 56), b"bc", b"bc")])
+def test_replace_encrypted_padded_pattern_blocked_scan(toy_k1, s, frm, to):
+    """The same with hidden lengths: `from` / `to` zero padded to capacity 4, any lengths, caller-given output capacity.
+    The scan's step then reads g[o] = match[o] * (L - 1) with the encrypted pattern length L."""
+    import fhestr
+    P = to_fhestr_params(O.TOY_K1)
+    want = s.replace(frm, to) if frm else s                 # an encrypted pattern that decrypts to "" replaces nothing
+    out_cap = max(len(want), 1)
+    plan = _plan(f"replace:4:{out_cap}", 56, 8)
+    inputs = np.concatenate([_enc(toy_k1, s, 56), _enc(toy_k1, frm, 4), _enc(toy_k1, to, 4)])
+    got = toy_k1.ck.decrypt_many(run_with_oracle(plan, inputs, toy_k1.sk))
+    assert fhestr.blocks_to_string(P, got) == want
+
+
+def test_blocked_scan_depth_at_1024_characters():
+    """The plan shape bench.py times as replace_enc_4_in_1024: 2 B + n / B levels for the scan instead of n / 2."""
+    import fhestr
+    P = to_fhestr_params(O.PARAM_MESSAGE_2_CARRY_2_KS_PBS)
+    plan = fhestr.Plan.string_op(None, "replace", 1024, 8, None, 1, params=P)
+    info = plan.info()
+    assert info["n_levels"] < 130, info
+    print("replace (encrypted 4-character pattern, 1024 characters):", info["n_levels"], "levels,", info["n_pbs"], "PBS")
