@@ -145,3 +145,57 @@ except fhestr.FheError as e:
     hooks.pop("FHESTR_CLUSTER_TEST_FAULT")
     r = subprocess.run([sys.executable, "-c", code, str(mode)], env=hooks, cwd=ROOT_DIR, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "NO ERROR" in r.stdout, r.stdout + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("shape,mode", [(O.TOY_N32768, 1), (O.TOY_N32768, 2), ([p for p in O.TOY_SHAPES if p.N == 16384][0], 1)],
+                         ids=lambda v: getattr(v, "name", str(v)))
+def test_cluster_launch_while_another_engine_holds_the_compute_units(p22, shape, mode):
+    """the multi-CU kernels need their whole grid resident at once.  Here a second engine keeps every CU
+    busy with long blind_rotate_wide_kernel batches (2,048 LWEs of PARAM_MESSAGE_2_CARRY_2, about 16 ms each, two workgroups per
+    CU) while cluster batches are launched from another stream at varying offsets into them.  Every cluster result must be
+    correct -- its workgroups queue until CUs free up, the formation wait is bounded but long enough -- or the call must raise
+    the documented 'hand-over timed out' error; a wrong ciphertext without an error is the one outcome that may not happen.
+    The other engine's results are checked too."""
+    import time
+    import fhestr
+    import torch
+    eng_a = gpu_engine(p22)
+    ks_b = keyset(shape)
+    eng_b = gpu_engine(ks_b)
+    pa = p22.params
+    Ma = pa.msg_mod * pa.carry_mod
+    lut_a, _ = eng_a.generate_lookup_table(lambda x: (x + 3) % Ma)
+    rng = np.random.default_rng(71)
+    msgs_a = rng.integers(0, Ma, size=2048)
+    d_in = torch.from_numpy(p22.ck.encrypt_many(msgs_a, O.Rng(71, 1)).view(np.int64)).cuda()
+    d_idx = torch.full((2048,), int(lut_a), dtype=torch.int32, device="cuda")
+    d_out = torch.zeros_like(d_in)
+    Mb = shape.msg_mod * shape.carry_mod
+    fb = lambda x: (5 * x + 1) % Mb
+    lut_b, _ = eng_b.generate_lookup_table(fb)
+    torch.cuda.synchronize()
+    eng_b.set_cluster_mode(mode)
+    timeouts = 0
+    try:
+        for trial in range(8):
+            count = (3, 8, 17, 40)[trial % 4]
+            msgs_b = rng.integers(0, Mb, size=count)
+            enc_b = ks_b.ck.encrypt_many(msgs_b, O.Rng(72, trial))
+            for _ in range(3):                           # ~50 ms of wide-kernel work queued on the other engine's stream
+                eng_a.apply_lookup_table_dev(d_in.data_ptr(), d_idx.data_ptr(), d_out.data_ptr(), 2048)
+            time.sleep(0.003 * (trial % 3))              # land at different points of the running batch
+            try:
+                got = eng_b.apply_lookup_table(enc_b, np.full(count, lut_b, dtype=np.uint32))
+                assert np.array_equal(ks_b.ck.decrypt_many(got), np.array([fb(int(m)) for m in msgs_b])), f"trial {trial}: silent garbage"
+            except fhestr.FheError as e:
+                assert "hand-over timed out" in str(e), str(e)
+                timeouts += 1
+            eng_a.synchronize()
+            assert np.array_equal(p22.ck.decrypt_many(d_out.cpu().numpy().view(np.uint64)[:64]), (msgs_a[:64] + 3) % Ma)
+    finally:
+        eng_b.set_cluster_mode(-1)
+    print(f"{shape.name} mode {mode}: {timeouts} of 8 launches reported a hand-over time-out, the rest were correct")
+    # after the contention: a clean launch works
+    enc_b = ks_b.ck.encrypt_many([1, 2, 3], O.Rng(73, 1))
+    got = eng_b.apply_lookup_table(enc_b, np.full(3, lut_b, dtype=np.uint32))
+    assert np.array_equal(ks_b.ck.decrypt_many(got), np.array([fb(m) for m in (1, 2, 3)]))

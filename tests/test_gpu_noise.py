@@ -88,6 +88,23 @@ def test_noise_model_against_measurement_per_kernel_family(key):
             assert e["max_abs_after_ms"] < 0.8 * r["half_box"]
 
 
+def test_multi_bit_group_2_keeps_the_reference_noise_rule():
+    """the packed compare (nu = 34) measured log2 p_fail = -38.6 on PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2
+    (the reference's own worst case on that set: -41.1).  Its budget is the reference's rule now, nu <= max_noise_level^2 = 25:
+    the planner falls back to the reference's bivariate compare there, and no PBS input of FheString::eq exceeds 25."""
+    import fhestr
+    from noise_budget import reference_params
+    P2 = reference_params("PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS")
+    P3 = reference_params("PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS")
+    assert fhestr.noise_model(P2)["budget"] <= 25.0 + 1e-9
+    assert fhestr.noise_model(P3)["budget"] >= 34.0            # measured -40.2 at nu = 34 with 4,096 samples
+    for P, packed in ((P2, False), (P3, True)):
+        plan = fhestr.Plan.string_op(None, "eq", 32, 32, None, 1, params=P)
+        ni = plan.noise_info()
+        assert ni["max_pbs_input_noise"] <= ni["budget"] + 1e-9
+        assert (ni["max_pbs_input_noise"] > 25.0) == packed, ni
+
+
 def test_uncalibrated_shapes_get_a_safety_factor():
     """A shape nobody measured must not inherit a budget from a constant fitted elsewhere."""
     import fhestr
@@ -97,3 +114,48 @@ def test_uncalibrated_shapes_get_a_safety_factor():
     m = fhestr.noise_model(P)
     max_level = (P.msg_mod * P.carry_mod - 1) / (P.msg_mod - 1)
     assert m["budget"] >= max_level ** 2 - 1e-9                   # never below the reference's own rule
+
+
+LARGE_N_SHAPES = [(next(p for p in O.TOY_SHAPES if p.name == "TOY_N8192_L1"), -1, 64),
+                  (next(p for p in O.TOY_SHAPES if p.name == "TOY_N16384_L2"), 1, 64),
+                  (O.TOY_N32768, 1, 48),      # all CUs of an XCD per LWE (pbs_xcd_kernels.hip.h)
+                  (O.TOY_N32768, 2, 48)]      # 8-CU clusters (pbs_cluster_kernels.hip.h)
+
+
+@pytest.mark.parametrize("params,mode,samples", LARGE_N_SHAPES, ids=lambda v: getattr(v, "name", str(v)))
+def test_large_n_transform_noise_against_the_oracles_f64_path_on_the_same_keys(params, mode, samples):
+    """the noise model's f64-FFT term for N >= 8192 was fitted on the engine it checks.  An
+    independent anchor: on the SAME keys and inputs, the error an f64 transform adds to a bootstrap is
+        phase(f64 implementation) - phase(exact-integer bootstrap),
+    and that is measured for the HIP path (four-step transforms over several CUs / through LDS) and for the oracle's f64
+    path (the reference's algorithm: one size-N/2 transform, fft64/math/fft/mod.rs:197-304) against tests/exact_pbs.py --
+    an exact-integer bootstrap fast enough for N = 32768, itself pinned bit for bit to the oracle's schoolbook path.
+    The two spreads must agree within [0.6, 1.6]: the GPU's transforms are no noisier than the reference algorithm's."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from exact_pbs import pbs_exact
+    ks = keyset(params)
+    eng = gpu_engine(ks)
+    M = params.msg_mod * params.carry_mod
+    lut, _ = ks.sk.generate_lookup_table(lambda x: x)
+    lut_id = eng.upload_lut(lut)
+    rng = np.random.default_rng(61)
+    msgs = rng.integers(0, M, size=samples)
+    cts = ks.ck.encrypt_many(msgs, O.Rng(6161, 2))
+    eng.set_cluster_mode(mode)
+    try:
+        gpu = eng.apply_lookup_table(cts, np.full(samples, lut_id, dtype=np.uint32))
+    finally:
+        eng.set_cluster_mode(-1)
+    f64 = ks.sk.apply_lookup_table_batch(cts, lut)
+    small = eng.keyswitch(cts)                                  # bit-identical to the oracle's (tests/test_gpu_parity.py)
+    exact = np.stack([pbs_exact(params, ks.sk.bsk, s, lut) for s in small])
+    phase = lambda cs: np.array([ks.ck.decrypt_plaintext(c) for c in cs], dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        e_gpu = (phase(gpu) - phase(exact)).astype(np.int64).astype(np.float64)
+        e_f64 = (phase(f64) - phase(exact)).astype(np.int64).astype(np.float64)
+    assert np.array_equal(ks.ck.decrypt_many(gpu), msgs) and np.array_equal(ks.ck.decrypt_many(exact), msgs)
+    s_gpu, s_f64 = e_gpu.std(), e_f64.std()
+    print(f"{params.name} mode {mode}: transform-induced phase error, std over {samples} bootstraps: HIP 2^{np.log2(s_gpu):.2f}, "
+          f"oracle f64 2^{np.log2(s_f64):.2f}, ratio {s_gpu / s_f64:.2f}; delta/2 = 2^{np.log2(params.delta / 2):.0f}")
+    assert 0.6 < s_gpu / s_f64 < 1.6
+    assert np.abs(e_gpu).max() < params.delta / 16
