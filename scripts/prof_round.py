@@ -43,7 +43,7 @@ def run(cmd, log):
 
 
 def short(name):
-    for k in ("blind_rotate_cluster_kernel", "blind_rotate_seq_kernel", "blind_rotate_large_kernel", "blind_rotate_wide_kernel",
+    for k in ("blind_rotate_xcd_kernel", "blind_rotate_cluster_kernel", "blind_rotate_seq_kernel", "blind_rotate_large_kernel", "blind_rotate_wide_kernel",
               "blind_rotate_multibit_kernel", "blind_rotate_kernel", "keyswitch_mfma_kernel", "ks_decompose_kernel",
               "keyswitch_dot4_kernel", "keyswitch_kernel", "lincomb_kernel"):
         if k in name:
@@ -57,6 +57,7 @@ def main():
     out = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     os.makedirs(out, exist_ok=True)
     custom = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--prog=")), None)
+    batch = int(next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--batch=")), 256))
     if custom:         # any other program of this repo, e.g. --prog="python3 scripts/param_sweep.py 256 8192 5_CARRY_1"
         prog = custom.split()
         stats_prog = prog
@@ -112,7 +113,7 @@ def main():
            "kernel_revision": rev, "command": " ".join(prog), "p44_command": " ".join(prog) if p44 else ""}
     for k, d in per_kernel.items():
         e = dict(d)
-        e["batch"] = 256
+        e["batch"] = batch
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             e["traffic_bytes_per_launch"] = int(2 * d["FETCH_SIZE"] * 1024 + d["WRITE_SIZE"] * 1024)
         if "TCC_HIT_sum" in d:
