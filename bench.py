@@ -30,8 +30,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-leve
 # FP64 vector peak: 256 CUs x 4 SIMDs x 16 f64 FMA lanes/clk x 2 FLOP x 2.4 GHz = half the guide's
 # 157.3 TF FP32 vector rate (one wave64 f64 instruction occupies its SIMD for >= 4 cycles)
 F64_VALU_PEAK_TFLOPS = 78.6
-COUNTERS = os.path.join(ROOT, "profiles", "r03_counters.json")   # written by scripts/prof_round.py (round 3 kernels)
-COUNTERS_P44 = os.path.join(ROOT, "profiles", "r03_p44_counters.json")   # the same for `scripts/p44_prof.py 256` (config 5)
+COUNTERS = os.path.join(ROOT, "profiles", "r04_counters.json")   # written by scripts/prof_round.py (this kernel revision)
+COUNTERS_P44 = os.path.join(ROOT, "profiles", "r04_p44_counters.json")   # the same for `scripts/p44_prof.py 256` (config 5)
 SEED = 0x5EED0002
 
 
@@ -371,7 +371,7 @@ def rooflines(P, B, world, value, br_avg_ms, revision, log2_points, kernel="blin
     """The `roofline` object of the bench contract (HBM, SURVEY 8(d)'s per-LWE key-streaming model for the
     dominant kernel) and, next to it, what actually bounds that kernel: f64 VALU issue + LDS
     (`roofline`; SURVEY's model is `roofline_hbm_model`).  Counter-derived fields come from the committed rocprofv3 passes
-    (profiles/r03_counters.json, one --pmc pass per counter set, scripts/prof_round.py) and are only
+    (profiles/r04_counters.json, one --pmc pass per counter set, scripts/prof_round.py) and are only
     attached when they were taken on this kernel revision, batch and variant."""
     br_bytes = P.bsk_len * 8 + P.glwe_len * 8 + P.small_size * 8 + P.big_size * 8   # BSK + LUT + LWE in/out
     achieved = concurrency * br_bytes * B / (br_avg_ms * 1e-3) / 1e9
@@ -382,7 +382,7 @@ def rooflines(P, B, world, value, br_avg_ms, revision, log2_points, kernel="blin
         cj = json.load(open(COUNTERS))
         c = cj[kernel]
         if c["batch"] == B and log2_points == 0 and cj.get("kernel_revision") == revision:
-            ctr, src = c, "profiles/r03_counters.json (static: rocprofv3 --pmc passes of this kernel revision, " + cj.get("command", "") + ")"
+            ctr, src = c, "profiles/r04_counters.json (static: rocprofv3 --pmc passes of this kernel revision, " + cj.get("command", "") + ")"
     except Exception:
         pass
     traffic = ctr["traffic_bytes_per_launch"] if ctr else None
@@ -510,7 +510,7 @@ def bench_p44(fhestr, local_rank):
                                    "frac": algo / (br_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "traffic": c["traffic_bytes_per_launch"], "l2_hit_rate": c.get("l2_hit_rate"),
                                    "traffic_gbs": c["traffic_bytes_per_launch"] / (br_avg_ms * 1e-3) / 1e9,
-                                   "traffic_source": "profiles/r03_p44_counters.json (static rocprofv3 --pmc passes, " + cj.get("p44_command", "") + ")"}
+                                   "traffic_source": "profiles/r04_p44_counters.json (static rocprofv3 --pmc passes, " + cj.get("p44_command", "") + ")"}
         except Exception:
             pass
         # config 5: 1024-char string, to_lower and replace (4-char clear pattern), one call each.  268 MB go each way:

@@ -28,6 +28,16 @@
 #pragma once
 #include "pbs_cluster_kernels.hip.h"
 
+// Cache policy of this kernel's Fourier-key loads: nt (2) -- streamed, not retained by the XCD's L2.  The 2 MB GGSW of a step is
+// read once per cluster; with the default policy (0) the two clusters' key streams (4 MB per step pair) push the exchange
+// matrices (2 x 1.6 MB) out of the 4 MB L2: L2 hit rate 0.64, 5.2 MB of fabric traffic per LWE-step, 18.5 ms per 16 LWEs; with
+// nt the exchange reads hit (0.78: the misses left are the key itself), 3.7 MB per LWE-step, 17.4 ms
+// (profiles/r04_xcd_history.txt).  The 8-CU cluster kernel keeps the default policy: its four clusters per XCD run in step and
+// share the key through L2 (nt there: 1,054 instead of 1,113 PBS/s, profiles/r03_cluster_history.txt).
+#ifndef FHESTR_XCD_KEY_AUX
+#define FHESTR_XCD_KEY_AUX 2
+#endif
+
 namespace fhe {
 
 template <int LOGN, int K1, int L>
@@ -228,7 +238,7 @@ blind_rotate_xcd_kernel(BlindRotateClusterArgs ca) {
                 for (int col = 0; col < K1; col++) {
 #pragma unroll
                     for (int rho = 0; rho < R; rho++) {
-                        const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, (int)voff_key, (col * P + rho * TB) * 16, FHESTR_CL_KEY_AUX);
+                        const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, (int)voff_key, (col * P + rho * TB) * 16, FHESTR_XCD_KEY_AUX);
                         __builtin_memcpy(&bv[col][rho], &raw, 16);
                     }
                 }
