@@ -485,7 +485,7 @@ def bench_p44(fhestr, local_rank):
                              "note": "SURVEY 8(d) per-LWE key-streaming model; bound 2.04 k PBS/s per GPU"}}
         # small batches: one LWE is worked on by a cluster of CUs, so latency no longer equals the 256-LWE step
         lat = {}
-        for nb in (1, 32):
+        for nb in (1, 16, 32):     # 1 and 16: the whole-XCD kernel (two LWEs in flight per XCD); 32 and above: the 8-CU clusters
             eng.apply_lookup_table_dev(d_in.data_ptr(), d_idx.data_ptr(), d_out.data_ptr(), nb)
             eng.synchronize()
             eng.kernel_times(reset=True)
@@ -497,13 +497,15 @@ def bench_p44(fhestr, local_rank):
         # roofline of the dominant kernel from the committed counters of this kernel revision: the bytes that crossed
         # the L2 <-> fabric boundary (FETCH_SIZE doubled for 16-byte-per-lane reads per MI355X_MICROARCH.md, WRITE_SIZE
         # as is, separate --pmc passes) against the HBM peak; algorithmic bytes = the cluster's exchange matrices
-        # (4 MB per LWE-step: 2 out + 2 back) + the 2 MB GGSW once per XCD and step
+        # (4 MiB per LWE-step: 2 out + 2 back) + the 2 MiB GGSW once per XCD, step and round of clusters (256 LWEs on 32
+        # clusters: 8 rounds)
         try:
             cj = json.load(open(COUNTERS_P44))
             c = cj.get(out["kernel"])
             if c and c.get("batch") == B and cj.get("kernel_revision") == fhestr.kernel_revision():
                 steps = P.n
-                algo = B * steps * 4 * (1 << 20) + steps * 8 * (P.bsk_len * 8 // P.n)
+                rounds = -(-B // max(clusters, 1))
+                algo = B * steps * 4 * (1 << 20) + steps * 8 * rounds * (P.bsk_len * 8 // P.n)
                 out["roofline"] = {"bound": "hbm", "kernel": out["kernel"], "avg_launch_ms": br_avg_ms,
                                    "algorithmic_bytes_per_launch": algo,
                                    "achieved": algo / (br_avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
