@@ -133,9 +133,14 @@ __device__ __forceinline__ uint64_t load_sc1_b64(RSRC rsrc, uint32_t voff) {
 // itself.  A wave that sees all C flags at this epoch knows that every wave of every member -- its own workgroup's
 // included -- has finished the phase, so the LDS planes may be reused as well.  The C flags of a cluster share one
 // 128-byte line (byte-masked stores into L2; one request per poll).
+// `need` (round 4): bit m set = this wave waits for member m.  The hand-over before a rotation gather needs only the (at
+// most two) members that own the wave's source columns: a global barrier becomes a local dependency there, and members
+// that run ahead absorb the jitter of the others.  All members still count every hand-over (epochs stay in step); a wave
+// that waits for fewer members may only touch LDS and global data those members' phase cannot still be using.
 template <int C, int PREFETCHED = 0, uint32_t WAVES = 8>
 __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, uint32_t& epoch, uint32_t* s_dead_generic,
-                                             ClusterCtl* ctl, ClusterStatus* status, uint32_t spin_limit, uint32_t mute_epoch) {
+                                             ClusterCtl* ctl, ClusterStatus* status, uint32_t spin_limit, uint32_t mute_epoch,
+                                             uint32_t need = 0xFFFFFFFFu) {
     typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32_t;
     lds_vu32_t* s_dead = (lds_vu32_t*)(uintptr_t)lds_address(s_dead_generic);
     const uint32_t arrive_address = lds_address(s_dead_generic + 1);          // the arrival counter sits behind the dead word
@@ -152,8 +157,10 @@ __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, u
     if (before + 1 == WAVES * epoch && lane == 0 && epoch != mute_epoch)
         __hip_atomic_store(flags + member, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     uint32_t spins = 0;
+    const bool polls = lane < (uint32_t)C && ((need >> lane) & 1u);
+    if (need == 0u) { asm volatile("" ::: "memory"); return; }
     for (;;) {
-        const uint32_t v = lane < (uint32_t)C ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+        const uint32_t v = polls ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
         if (__all((int32_t)(v - epoch) >= 0)) break;
         ++spins;
         const bool others_gave_up = (spins & 1023u) == 0 && (*s_dead || __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -171,7 +178,8 @@ __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, u
 #else
 template <int C, int PREFETCHED = 0, uint32_t WAVES = 8>
 __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, uint32_t& epoch, uint32_t* s_dead_generic,
-                                             ClusterCtl* ctl, ClusterStatus* status, uint32_t spin_limit, uint32_t mute_epoch) {
+                                             ClusterCtl* ctl, ClusterStatus* status, uint32_t spin_limit, uint32_t mute_epoch,
+                                             uint32_t /* need: this variant always waits for everyone */ = 0xFFFFFFFFu) {
     typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32_t;     // a plain LDS access (a generic pointer would be a
     lds_vu32_t* s_dead = (lds_vu32_t*)(uintptr_t)lds_address(s_dead_generic);   // flat load: it waits for vmcnt(0) as well)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PREFETCHED) : "memory");      // this wave's stores have reached L2
@@ -621,7 +629,21 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
                 }
             }
             FHE_STAMP(5);
-            cluster_sync<C>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch);
+            // hand-over 3 guards the NEXT step's rotation gather only: this wave's four columns come from at most two members
+            // (column b of acc X^d is column b - rb of acc), so it waits for those and no others (cluster_sync, `need`).
+            // The T stores of the next phase 1 touch this workgroup's own columns only, which no other member reads in phase 3,
+            // and the last step of an LWE needs nobody: the next LWE starts with a full hand-over.
+            uint32_t need3 = 0;
+            {
+                uint32_t j = i + 1;
+                while (j < n && lds_d[j] == 0xFFFFFFFFu) j++;
+                if (j < n) {
+                    const uint32_t rbn = lds_d[j] & (P2 - 1);
+                    const uint32_t mine = 1u << ((((uint32_t)b - rbn) & (P2 - 1)) / (uint32_t)CFG::COLS);
+                    need3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine) | (uint32_t)__builtin_amdgcn_readlane((int)mine, 63);
+                }
+            }
+            cluster_sync<C>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch, need3);
             FHE_STAMP(6);
         }
 #ifdef FHESTR_STAMPS

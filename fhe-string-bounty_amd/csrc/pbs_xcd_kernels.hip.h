@@ -228,7 +228,9 @@ blind_rotate_xcd_kernel(BlindRotateClusterArgs ca) {
             // The GGSW rows this group multiplies by in phase 2 (16 x 16 bytes per thread: 2 MB per step and cluster, from the
             // Infinity Cache or HBM) are requested inside phase 1 -- by the partner waves at once, by the owners as soon as their
             // gather has been consumed (vector-memory loads return in order: nothing the phase waits for may queue behind them).
-            // Requested just before hand-over 1 instead, they held every wave's flag polls back for 4 us (profiles/r04_xcd_history.txt).
+            // Requested just before hand-over 1 instead, they held every wave's flag polls back for 4 us; requested by the partner
+            // waves in the PREVIOUS step's phase 3 (where they idle) they sit in front of the owners' T' loads -- a CU serves its
+            // waves' vector-memory requests in order: 13.4 instead of 11.0 ms per 8 LWEs (profiles/r04_xcd_history.txt).
             const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(args.fbsk)) + (size_t)i * GGSW_BYTES, 0, (int)GGSW_BYTES,
                 0x00020000);
@@ -396,7 +398,20 @@ blind_rotate_xcd_kernel(BlindRotateClusterArgs ca) {
                 }
             }
             FHE_STAMP(5);
-            cluster_sync<C, 0, WAVES>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch);
+            // hand-over 3 guards the next step's rotation gather only: an owner wave waits for the (at most two) members that own
+            // its source columns, a partner wave for nobody (it meets its owner at the LDS barrier of phase 1); the last step of
+            // an LWE needs nobody (pbs_cluster_kernels.hip.h: cluster_sync, `need`)
+            uint32_t need3 = 0;
+            if (owner) {
+                uint32_t j = i + 1;
+                while (j < n && lds_d[j] == 0xFFFFFFFFu) j++;
+                if (j < n) {
+                    const uint32_t rbn = lds_d[j] & (P2 - 1);
+                    const uint32_t mine = 1u << ((((uint32_t)b - rbn) & (P2 - 1)) / (uint32_t)CFG::COLS);
+                    need3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine) | (uint32_t)__builtin_amdgcn_readlane((int)mine, 63);
+                }
+            }
+            cluster_sync<C, 0, WAVES>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch, need3);
             FHE_STAMP(6);
         }
 #ifdef FHESTR_STAMPS
