@@ -122,8 +122,8 @@ __device__ __forceinline__ uint64_t load_sc1_b64(RSRC rsrc, uint32_t voff) {
 // All C workgroups of the cluster have stored what the next phase reads.  A wait that does not end within
 // CLUSTER_SPIN_LIMIT polls marks the launch dead (LDS word + ctl->error + the sticky status): every later wait of
 // every cluster returns at once, the kernel drains with garbage and the host reports it (Engine::cluster_check).
-// PREFETCHED: vector-memory loads the caller issued AFTER its last store and wants to keep in flight across the
-// hand-over (vmcnt counts loads and stores together, in issue order: all but the youngest PREFETCHED are done).
+// Every wave drains its vector-memory queue completely (vmcnt(0)): waiting for "all but the N youngest" operations would
+// rest on the compiler placing nothing -- no scratch spill either -- behind the caller's prefetches.
 #ifndef FHESTR_CL_SYNC
 #define FHESTR_CL_SYNC 1
 #endif
@@ -137,16 +137,21 @@ __device__ __forceinline__ uint64_t load_sc1_b64(RSRC rsrc, uint32_t voff) {
 // most two) members that own the wave's source columns: a global barrier becomes a local dependency there, and members
 // that run ahead absorb the jitter of the others.  All members still count every hand-over (epochs stay in step); a wave
 // that waits for fewer members may only touch LDS and global data those members' phase cannot still be using.
-template <int C, int PREFETCHED = 0, uint32_t WAVES = 8>
+template <int C, uint32_t WAVES = 8>
 __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, uint32_t& epoch, uint32_t* s_dead_generic,
                                              ClusterCtl* ctl, ClusterStatus* status, uint32_t spin_limit, uint32_t mute_epoch,
                                              uint32_t need = 0xFFFFFFFFu) {
     typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32_t;
     lds_vu32_t* s_dead = (lds_vu32_t*)(uintptr_t)lds_address(s_dead_generic);
-    const uint32_t arrive_address = lds_address(s_dead_generic + 1);          // the arrival counter sits behind the dead word
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PREFETCHED) : "memory");         // this wave's stores have reached L2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this wave's stores have reached L2
     ++epoch;
     if (*s_dead) return;
+    // Two arrival counters behind the dead word, used in turn by even and odd epochs and reset by the wave that completes the
+    // count: with `need`, a wave may be ONE hand-over ahead of its slowest workgroup-mate (never two: the hand-over after a
+    // partial one waits for every member, this workgroup included), so arrivals of two consecutive epochs can interleave and
+    // must not share a counter (a single running count published nothing when they did: the flag of epoch e then only appeared
+    // with epoch e + 1).  The reset is ordered before the resetting wave's own next arrival, which every arrival at epoch + 2 follows.
+    const uint32_t arrive_address = lds_address(s_dead_generic + 1 + (epoch & 1u));
     const uint32_t lane = threadIdx.x & 63;
     uint32_t before = 0;
     if (lane == 0) {
@@ -154,8 +159,11 @@ __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, u
         asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(before) : "v"(arrive_address), "v"(one) : "memory");
     }
     before = __builtin_amdgcn_readfirstlane(before);
-    if (before + 1 == WAVES * epoch && lane == 0 && epoch != mute_epoch)
-        __hip_atomic_store(flags + member, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (before + 1 == WAVES && lane == 0) {
+        const uint32_t zero = 0;
+        asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(arrive_address), "v"(zero) : "memory");
+        if (epoch != mute_epoch) __hip_atomic_store(flags + member, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     uint32_t spins = 0;
     const bool polls = lane < (uint32_t)C && ((need >> lane) & 1u);
     if (need == 0u) { asm volatile("" ::: "memory"); return; }
@@ -176,13 +184,13 @@ __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, u
     asm volatile("" ::: "memory");
 }
 #else
-template <int C, int PREFETCHED = 0, uint32_t WAVES = 8>
+template <int C, uint32_t WAVES = 8>
 __device__ __forceinline__ void cluster_sync(uint32_t* flags, uint32_t member, uint32_t& epoch, uint32_t* s_dead_generic,
                                              ClusterCtl* ctl, ClusterStatus* status, uint32_t spin_limit, uint32_t mute_epoch,
                                              uint32_t /* need: this variant always waits for everyone */ = 0xFFFFFFFFu) {
     typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32_t;     // a plain LDS access (a generic pointer would be a
     lds_vu32_t* s_dead = (lds_vu32_t*)(uintptr_t)lds_address(s_dead_generic);   // flat load: it waits for vmcnt(0) as well)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PREFETCHED) : "memory");      // this wave's stores have reached L2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's stores have reached L2
     __syncthreads();
     ++epoch;
     if (threadIdx.x < 64 && !*s_dead) {
@@ -218,6 +226,7 @@ template <int C>
 __device__ __forceinline__ void cluster_join(ClusterCtl* ctl, ClusterStatus* status, uint32_t spin_limit, uint32_t* s_form, uint32_t* s_sync) {
     s_sync[0] = 0;
     s_sync[1] = 0;
+    s_sync[2] = 0;
     uint32_t xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7u;
@@ -260,6 +269,7 @@ template <int C>
 __device__ __forceinline__ void cluster_join_per_cu(ClusterCtl* ctl, ClusterStatus* status, uint32_t spin_limit, uint32_t* s_form, uint32_t* s_sync) {
     s_sync[0] = 0;
     s_sync[1] = 0;
+    s_sync[2] = 0;
     uint32_t xcc, hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -313,7 +323,7 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     __shared__ uint32_t s_form[4];
-    __shared__ uint32_t s_sync[2];        // [0] dead flag, [1] arrival counter of the hand-overs
+    __shared__ uint32_t s_sync[4];        // [0] dead flag, [1], [2] arrival counters of the hand-overs (even / odd epochs)
     uint32_t& s_dead = s_sync[0];
 
     const int tid = threadIdx.x;
@@ -452,6 +462,26 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
                 g_wall[cluster * 8 + i / (n / 8)] = __builtin_amdgcn_s_memrealtime();
 #endif
 
+            // the GGSW rows of this half's first digit polynomial do not depend on the hand-over: request them now
+            const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(args.fbsk)) +
+#ifdef FHESTR_CL_KEY0      // diagnostic build: every step reads the first GGSW (wrong results; what does the key stream cost?)
+                    (size_t)0 * GGSW_BYTES,
+#else
+                    (size_t)i * GGSW_BYTES,
+#endif
+                    0, (int)GGSW_BYTES, 0x00020000);
+            double2 bv[K1][R];
+            auto issue_key = [&](int uu) {
+#pragma unroll
+                for (int col = 0; col < K1; col++) {
+#pragma unroll
+                    for (int rho = 0; rho < R; rho++) {
+                        const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, (int)voff_key[uu], (col * P + rho * TB) * 16, FHESTR_CL_KEY_AUX);
+                        __builtin_memcpy(&bv[col][rho], &raw, 16);
+                    }
+                }
+            };
             // ---- phase 1: rotate, subtract, decompose, twist, column transforms, twiddle -> T ----
             {
                 using state_t = typename std::conditional<(L >= 3), uint64_t, uint32_t>::type;
@@ -479,6 +509,17 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
                 }
 #pragma unroll
                 for (int it = 0; it < L; it++) {
+                    if (it == L - 1) {
+                        // The first key rows of phase 2, requested before the phase's LAST transform round.  Round 3 requested them
+                        // just before hand-over 1 and let the hand-over wait with s_waitcnt vmcnt(16) "for everything but the 16
+                        // youngest loads": that silently assumes the compiler puts no other vector-memory instruction -- a
+                        // register spill to scratch is one -- behind them, and a change of register allocation in round 4 broke
+                        // exactly that (wrong ciphertexts, caught by tests/test_gpu_cluster.py).  Every hand-over drains the
+                        // wave's queue completely now; by then these loads have had a transform round to arrive (same speed).
+                        asm volatile("" ::: "memory");
+                        issue_key(0);
+                        asm volatile("" ::: "memory");
+                    }
                     cplx x[R];
 #pragma unroll
                     for (int m = 0; m < R; m++) {
@@ -508,30 +549,7 @@ blind_rotate_cluster_kernel(BlindRotateClusterArgs ca) {
                 }
             }
             FHE_STAMP(1);
-            // the GGSW rows of this half's first digit polynomial do not depend on the hand-over: request them now
-            const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(args.fbsk)) +
-#ifdef FHESTR_CL_KEY0      // diagnostic build: every step reads the first GGSW (wrong results; what does the key stream cost?)
-                    (size_t)0 * GGSW_BYTES,
-#else
-                    (size_t)i * GGSW_BYTES,
-#endif
-                    0, (int)GGSW_BYTES, 0x00020000);
-            double2 bv[K1][R];
-            auto issue_key = [&](int uu) {
-#pragma unroll
-                for (int col = 0; col < K1; col++) {
-#pragma unroll
-                    for (int rho = 0; rho < R; rho++) {
-                        const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, (int)voff_key[uu], (col * P + rho * TB) * 16, FHESTR_CL_KEY_AUX);
-                        __builtin_memcpy(&bv[col][rho], &raw, 16);
-                    }
-                }
-            };
-            asm volatile("" ::: "memory");         // after the phase's stores in issue order
-            issue_key(0);
-            asm volatile("" ::: "memory");
-            cluster_sync<C, K1 * R>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch);
+            cluster_sync<C>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch);
             FHE_STAMP(2);
 
             // ---- phase 2: row transforms, multiply-accumulate with the GGSW, inverse row transforms, in place ----

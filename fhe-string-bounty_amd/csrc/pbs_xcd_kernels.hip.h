@@ -95,7 +95,7 @@ blind_rotate_xcd_kernel(BlindRotateClusterArgs ca) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     __shared__ uint32_t s_form[4];
-    __shared__ uint32_t s_sync[2];        // [0] dead flag, [1] arrival counter of the hand-overs
+    __shared__ uint32_t s_sync[4];        // [0] dead flag, [1], [2] arrival counters of the hand-overs (even / odd epochs)
     uint32_t& s_dead = s_sync[0];
 
     const int tid = threadIdx.x;
@@ -217,7 +217,7 @@ blind_rotate_xcd_kernel(BlindRotateClusterArgs ca) {
                 }
             }
         }
-        cluster_sync<C, 0, WAVES>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch);
+        cluster_sync<C, WAVES>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch);
 
         FHE_STAMP_DECL;
         FHE_STAMP(-1);
@@ -315,7 +315,7 @@ blind_rotate_xcd_kernel(BlindRotateClusterArgs ca) {
                 }
             }
             FHE_STAMP(1);
-            cluster_sync<C, 0, WAVES>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch);
+            cluster_sync<C, WAVES>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch);
             FHE_STAMP(2);
 
             // ---- phase 2: row transforms, multiply by the GGSW row, reduce, inverse row transforms, in place ----
@@ -368,7 +368,7 @@ blind_rotate_xcd_kernel(BlindRotateClusterArgs ca) {
                 }
             }
             FHE_STAMP(8);
-            cluster_sync<C, 0, WAVES>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch);
+            cluster_sync<C, WAVES>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch);
             FHE_STAMP(4);
 
             // ---- phase 3 (owner waves): inverse column transforms, untwist, torus rounding, accumulate, publish ----
@@ -411,7 +411,7 @@ blind_rotate_xcd_kernel(BlindRotateClusterArgs ca) {
                     need3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine) | (uint32_t)__builtin_amdgcn_readlane((int)mine, 63);
                 }
             }
-            cluster_sync<C, 0, WAVES>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch, need3);
+            cluster_sync<C, WAVES>(flags, member, epoch, &s_dead, ctl, ca.status, ca.spin_limit, mute_epoch, need3);
             FHE_STAMP(6);
         }
 #ifdef FHESTR_STAMPS
