@@ -1,4 +1,4 @@
-"""Soak of blind_rotate_cluster_kernel under uneven load (GPU box): many launches of 256 and of odd batch sizes on
+"""Soak of blind_rotate_cluster_kernel / blind_rotate_xcd_kernel under uneven load (GPU box): many launches of 256 and of odd batch sizes on
 PARAM_MESSAGE_4_CARRY_4 (N = 32768) and PARAM_MESSAGE_3_CARRY_4 (N = 16384), a second stream hammering HBM with copies
 of changing size at the same time (so the clusters of different XCDs run at different speeds and the L2s see foreign
 traffic), every output decrypted.  A stale hand-over (a consumer reading an exchange buffer before the producer's bytes
@@ -49,13 +49,13 @@ try:
         g, s = ck.secret_keys()
         eng = fhestr.Engine(P, 0)
         eng.generate_keys(g, s, 9)
-        eng.set_cluster_mode(1)
         rng = np.random.default_rng(2)
         table = rng.integers(0, M, size=M)
         lut, _ = eng.generate_lookup_table(lambda x: int(table[x]))
         t0 = time.time()
         for it in range(launches):
-            B = 256 if it % 3 == 0 else int(rng.integers(1, 300))
+            eng.set_cluster_mode((1, 2, -1)[it % 3])     # whole-XCD kernel (where it exists), 8-CU clusters, automatic
+            B = 256 if it % 4 == 0 else int(rng.integers(1, 300))
             msgs = rng.integers(0, M, size=B)
             out = eng.apply_lookup_table(ck.encrypt(msgs), np.full(B, lut, dtype=np.uint32))
             wrong = int((ck.decrypt(out) != table[msgs]).sum())
