@@ -41,6 +41,21 @@ uint64_t fill_accumulator(const fhe_params_t& p, const uint64_t* table, std::vec
 // the same from torus values per box (tables whose entries are not multiples of delta: Circuit::pbs_full_box)
 void fill_accumulator_torus(const fhe_params_t& p, const uint64_t* box_values, std::vector<uint64_t>& acc);
 
+// Environment switches (diagnostics / A/B measurements only; -1 or -2 = not set).  Read once per engine, engine.hip: EngineEnv::read.
+struct EngineEnv {
+    int log2_points = 0;              // FHESTR_LOG2_POINTS          blind-rotation variant selector (fhe_engine_set_variant)
+    int wide_fair = -1;               // FHESTR_WIDE_FAIR            log2 ticks of the two-LWEs-per-CU kernel's priority slices, 0 = off
+    int keep_busy = -1;               // FHESTR_KEEP_BUSY            fhe_engine_set_keep_busy at creation
+    int overlap_streams = -1;         // FHESTR_OVERLAP_STREAMS      streams of throughput mode 2 (2 .. 4)
+    int ks_mfma = -1;                 // FHESTR_KS_MFMA              0: byte-plane keyswitch kernel everywhere
+    int ks_chunks = -1;               // FHESTR_KS_CHUNKS            K chunks of the matrix-core keyswitch
+    int cluster_mode = -2;            // FHESTR_CLUSTER              fhe_engine_set_cluster_mode at creation (-1 .. 2)
+    int cluster_spin_limit = -1;      // FHESTR_CLUSTER_SPIN_LIMIT   polls before a hand-over wait gives up
+    int multibit_combine_max = -1;    // FHESTR_MULTIBIT_COMBINE_MAX fhe_engine_set_multibit_combine_max at creation
+    int cluster_test_fault = -1;      // FHESTR_CLUSTER_TEST_FAULT   honoured by the -DFHESTR_TEST_HOOKS build only
+    static EngineEnv read();
+};
+
 struct Engine {
     std::recursive_mutex mu;      // taken by every C ABI entry point that touches this engine (c_api.cpp, LOCK_ENGINE)
     fhe_params_t p{};
@@ -108,6 +123,7 @@ struct Engine {
     uint32_t cluster_last = 0;      // clusters the last checked launch formed
     int cluster_mode = -1;          // -1 automatic (by batch size), 0 never, 1 always (FHESTR_CLUSTER)
     uint32_t cluster_max_batch = 0xFFFFFFFFu;
+    uint32_t ks_chunks_override = 0; // FHESTR_KS_CHUNKS: K chunks of the matrix-core keyswitch (0 = automatic)
     uint32_t xcd_auto_max = 16;     // automatic mode: batches up to this size take the whole-XCD kernel (two LWEs per XCD in flight)
     uint32_t cluster_spin_limit = 1u << 22;   // polls before a hand-over wait gives up (FHESTR_CLUSTER_SPIN_LIMIT)
     uint32_t cluster_test_fault = 0;          // tests only (FHESTR_CLUSTER_TEST_FAULT): epoch one workgroup stays silent at

@@ -280,9 +280,27 @@ int params_supported(const fhe_params_t& p, int selector, const BrVariant** out_
 }
 int params_supported(const fhe_params_t& p) { return params_supported(p, 0, nullptr); }
 
+// Every environment switch of the library in one place, read when an engine is created.  They exist for diagnostics and A/B
+// measurements (scripts/); the product interface is the API: fhe_engine_set_variant / _set_pipeline / _set_keep_busy /
+// _set_cluster_mode / _set_multibit_combine_max.
+EngineEnv EngineEnv::read() {
+    EngineEnv v;
+    auto num = [](const char* name, int& out) { if (const char* t = getenv(name)) out = atoi(t); };
+    num("FHESTR_LOG2_POINTS", v.log2_points);
+    num("FHESTR_WIDE_FAIR", v.wide_fair);
+    num("FHESTR_KEEP_BUSY", v.keep_busy);
+    num("FHESTR_OVERLAP_STREAMS", v.overlap_streams);
+    num("FHESTR_KS_MFMA", v.ks_mfma);
+    num("FHESTR_KS_CHUNKS", v.ks_chunks);
+    num("FHESTR_CLUSTER", v.cluster_mode);
+    num("FHESTR_CLUSTER_SPIN_LIMIT", v.cluster_spin_limit);
+    num("FHESTR_MULTIBIT_COMBINE_MAX", v.multibit_combine_max);
+    num("FHESTR_CLUSTER_TEST_FAULT", v.cluster_test_fault);
+    return v;
+}
+
 int Engine::create(const fhe_params_t& p, int device, Engine** out) {
-    int env_logr = 0;
-    if (const char* e = getenv("FHESTR_LOG2_POINTS")) env_logr = atoi(e);
+    const int env_logr = EngineEnv::read().log2_points;
     const BrVariant* v = nullptr;
     if (params_supported(p, env_logr, &v)) return 1;
     int count = 0;
@@ -295,16 +313,18 @@ int Engine::create(const fhe_params_t& p, int device, Engine** out) {
     e->device = device;
     e->variant = v;
     e->variant_large = v;
-    if (const char* m = getenv("FHESTR_WIDE_FAIR")) e->wide_fair_shift = (uint32_t)std::min(20, std::max(0, atoi(m)));
-    if (const char* m = getenv("FHESTR_KEEP_BUSY")) e->keep_busy = atoi(m) != 0;
-    if (const char* m = getenv("FHESTR_OVERLAP_STREAMS")) e->ovl_streams = std::min((int)Engine::OVL_MAX, std::max(2, atoi(m)));
-    if (const char* m = getenv("FHESTR_KS_MFMA")) e->ks_mfma_enabled = atoi(m) != 0;
-    if (const char* m = getenv("FHESTR_CLUSTER_SPIN_LIMIT")) e->cluster_spin_limit = (uint32_t)std::max(64, atoi(m));
+    const EngineEnv env = EngineEnv::read();
+    if (env.wide_fair >= 0) e->wide_fair_shift = (uint32_t)std::min(20, env.wide_fair);
+    if (env.keep_busy >= 0) e->keep_busy = env.keep_busy != 0;
+    if (env.overlap_streams >= 0) e->ovl_streams = std::min((int)Engine::OVL_MAX, std::max(2, env.overlap_streams));
+    if (env.ks_mfma >= 0) e->ks_mfma_enabled = env.ks_mfma != 0;
+    if (env.ks_chunks >= 0) e->ks_chunks_override = (uint32_t)env.ks_chunks;
+    if (env.cluster_spin_limit >= 0) e->cluster_spin_limit = (uint32_t)std::max(64, env.cluster_spin_limit);
+    if (env.cluster_mode > -2) e->cluster_mode = std::min(2, std::max(-1, env.cluster_mode));
+    if (env.multibit_combine_max >= 0) e->multibit_combine_max = (uint32_t)std::min(1024, env.multibit_combine_max);
 #ifdef FHESTR_TEST_HOOKS      // fault injection exists only in the test build (make testhooks), never in the product library
-    if (const char* m = getenv("FHESTR_CLUSTER_TEST_FAULT")) e->cluster_test_fault = (uint32_t)std::max(0, atoi(m));
+    if (env.cluster_test_fault >= 0) e->cluster_test_fault = (uint32_t)env.cluster_test_fault;
 #endif
-    if (const char* m = getenv("FHESTR_CLUSTER")) e->cluster_mode = std::min(2, std::max(-1, atoi(m)));
-    if (const char* m = getenv("FHESTR_MULTIBIT_COMBINE_MAX")) e->multibit_combine_max = (uint32_t)std::min(1024, std::max(0, atoi(m)));
     if (env_logr == 0) {   // automatic: "wide" twin (same points per thread => same key layout) for big batches
         const BrVariant* w = find_variant(p, v->logR | 16);
         if (w) e->variant_large = w;
@@ -717,7 +737,7 @@ int Engine::launch_keyswitch(const uint64_t* d_big, uint64_t* d_sm, uint32_t cou
         // chunk adds batch x columns 64-bit atomics (measured at 256 LWEs: 8 chunks 55 us, 32 chunks 89 us for memset +
         // digits + product; scripts/ks_bench.py)
         uint32_t chunks = (6u * (uint32_t)cu_count + g.col_groups * gy * mt / 2) / (g.col_groups * gy * mt);
-        if (const char* e = getenv("FHESTR_KS_CHUNKS")) chunks = (uint32_t)atoi(e);
+        if (ks_chunks_override) chunks = ks_chunks_override;
         chunks = std::max(1u, std::min(chunks, (g.steps + 7) / 8));
         chunks = std::max(chunks, (g.steps + ks_mfma_max_steps(p.ks_base_log) - 1) / ks_mfma_max_steps(p.ks_base_log));   // int32 accumulators
         const uint32_t spc = (g.steps + chunks - 1) / chunks;
