@@ -143,6 +143,30 @@ def test_p22_replace_encrypted_pattern_64_chars_blocked_scan(p22, s, frm, to):
     assert fhestr.blocks_to_string(P, _dec(p22, padded)) == want
 
 
+def test_replace_blocked_scan_fuzz(toy_k1):
+    """Random strings over {a, b} (overlapping candidates everywhere), 50 .. 72 characters, encrypted patterns of 2 .. 4
+    characters: unpadded in place (two offsets per scan step where 4 m <= 16) and zero padded with hidden lengths, against
+    bytes.replace.  60 cases on the toy parameter set."""
+    import fhestr
+    ops = _ops(toy_k1)
+    P = gpu_engine(toy_k1).params
+    rng = np.random.default_rng(0x5CA9)
+    for case in range(60):
+        cap = int(rng.integers(50, 73))
+        n = int(rng.integers(cap - 8, cap + 1))
+        s = bytes(rng.choice(np.frombuffer(b"ab", dtype=np.uint8), size=n))
+        m = int(rng.integers(2, 5))
+        frm = bytes(rng.choice(np.frombuffer(b"ab", dtype=np.uint8), size=m))
+        to = bytes(rng.choice(np.frombuffer(b"XYZ", dtype=np.uint8), size=m))
+        want = s.replace(frm, to)
+        es = _enc(toy_k1, s, cap)
+        if case % 2 == 0:
+            out = ops.replace(es, _enc(toy_k1, frm, m), _enc(toy_k1, to, m))
+        else:
+            out = ops.replace(es, _enc(toy_k1, frm, 4), _enc(toy_k1, to, 4), out_cap=cap)
+        assert fhestr.blocks_to_string(P, _dec(toy_k1, out)) == want, (case, s, frm, to)
+
+
 def test_plan_matches_oracle_execution(toy_k1):
     """Same plan, same inputs: GPU executor vs the oracle stepping through the exported levels."""
     import fhestr
