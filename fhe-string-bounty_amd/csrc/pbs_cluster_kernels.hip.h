@@ -30,7 +30,9 @@
 #pragma once
 #include "pbs_large_kernels.hip.h"
 
+#ifndef FHESTR_CL_KEY_AUX
 #define FHESTR_CL_KEY_AUX 0       // Fourier-key loads: default policy (shared by the clusters of an XCD through L2)
+#endif
 
 // cache policy of the loads of exchanged data: sc1 = past the vector L1, served by the XCD's L2.  (Measured and dropped:
 // sc1 | nt on these loads, nt on the key loads, and starting half of an XCD's clusters half a step late -- all within
