@@ -8,6 +8,10 @@ print("roofline", {k: d["roofline"][k] for k in ("bound", "achieved", "frac", "a
 for k, v in (d.get("string_ops") or {}).items():
     if isinstance(v, dict):
         host = v.get('ms_per_op_inputs_from_host')
+        if "instances_per_rank" in v:      # many instances per pass (fhe_plan_run_batch)
+            print(f"  {k}: {v['ms_per_op']:.2f} ms per op ({v['instances_per_rank']} per pass, {v['ms_per_pass']:.1f} ms per pass), "
+                  f"{v['pbs_per_s']:.0f} PBS/s, correct {v['correct']}")
+            continue
         print(f"  {k}: {v['ms_per_op']:.2f} ms resident, " + (f"{host:.2f} ms from host, " if host else "") + f"{v['n_pbs']} PBS, correct {v['correct']}")
 p = d.get("p44") or {}
 if p:
