@@ -45,7 +45,7 @@ def run(cmd, log):
 def short(name):
     for k in ("blind_rotate_xcd_kernel", "blind_rotate_cluster_kernel", "blind_rotate_seq_kernel", "blind_rotate_large_kernel", "blind_rotate_wide_kernel",
               "blind_rotate_multibit_kernel", "blind_rotate_kernel", "keyswitch_mfma_kernel", "ks_decompose_kernel",
-              "keyswitch_dot4_kernel", "keyswitch_kernel", "lincomb_kernel"):
+              "keyswitch_dot4_kernel", "lincomb_kernel"):
         if k in name:
             return k
     return name[:60]
