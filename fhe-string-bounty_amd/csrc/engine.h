@@ -124,6 +124,7 @@ struct Engine {
     int cluster_mode = -1;          // -1 automatic (by batch size), 0 never, 1 always (FHESTR_CLUSTER)
     uint32_t cluster_max_batch = 0xFFFFFFFFu;
     uint32_t ks_chunks_override = 0; // FHESTR_KS_CHUNKS: K chunks of the matrix-core keyswitch (0 = automatic)
+    int xcd_per_cu = -1;             // workgroups of the whole-XCD kernel a CU holds (occupancy query, cached)
     uint32_t xcd_auto_max = 16;     // automatic mode: batches up to this size take the whole-XCD kernel (two LWEs per XCD in flight)
     uint32_t cluster_spin_limit = 1u << 22;   // polls before a hand-over wait gives up (FHESTR_CLUSTER_SPIN_LIMIT)
     uint32_t cluster_test_fault = 0;          // tests only (FHESTR_CLUSTER_TEST_FAULT): epoch one workgroup stays silent at

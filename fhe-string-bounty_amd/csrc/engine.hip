@@ -858,10 +858,13 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
         // per CU (the dynamic LDS request is padded past half a CU's LDS so that no CU takes two).  More: two clusters per
         // XCD, i.e. two workgroups on every CU -- the grid is exactly what the device holds, every workgroup must be resident.
         const uint32_t C = (uint32_t)v->xcd_size, quantum = 8 * C;
-        int per_cu = 0;
         const size_t lds2 = v->xcd_lds + (size_t)p.n * 4;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v->xcd_fn, v->xcd_threads, lds2));
-        const uint32_t rounds = (count > 8 && per_cu >= 2) ? 2u : 1u;
+        if (xcd_per_cu < 0) {       // once per engine: do two of its workgroups fit a CU?  (registers, LDS: asked, not assumed)
+            int per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v->xcd_fn, v->xcd_threads, lds2));
+            xcd_per_cu = per_cu;
+        }
+        const uint32_t rounds = (count > 8 && xcd_per_cu >= 2) ? 2u : 1u;
         const uint32_t max_clusters = std::min<uint32_t>((uint32_t)CLUSTER_MAX, ((uint32_t)cu_count / quantum) * 8 * rounds);
         const uint32_t want = std::min(count, max_clusters);
         const uint32_t grid = (want + 7) / 8 * quantum;
