@@ -358,6 +358,44 @@ def bench_multi_bit(fhestr, local_rank, B, steps):
     return out
 
 
+def bench_n1024_k2(fhestr, local_rank):
+    """PARAM_MESSAGE_2_CARRY_1_KS_PBS (N = 1024, k = 2: the other polynomial size BASELINE.json's north_star names): KS+PBS
+    steps of 256 LWEs (one per CU), 512 (two per CU) and 2,048 (the dense kernel, four per CU), decrypt-checked."""
+    import torch
+    P = fhestr.PARAM_MESSAGE_2_CARRY_1_KS_PBS
+    M = P.msg_mod * P.carry_mod
+    ck = fhestr.ClientKey(P, SEED + 2)
+    g, s = ck.secret_keys()
+    eng = fhestr.Engine(P, local_rank)
+    try:
+        eng.generate_keys(g, s, SEED + 2)
+        rng = np.random.default_rng(SEED + 2)
+        table = rng.integers(0, M, size=M)
+        lut, _ = eng.generate_lookup_table(lambda x: int(table[x]))
+        rec = {"params": P.name}
+        for nb in (256, 512, 2048):
+            msgs = rng.integers(0, M, size=nb)
+            d_in = torch.from_numpy(ck.encrypt(msgs).view(np.int64)).cuda()
+            d_idx = torch.full((nb,), int(lut), dtype=torch.int32, device="cuda")
+            d_out = torch.zeros_like(d_in)
+            for it in range(8):
+                if it == 3:
+                    eng.synchronize()
+                    eng.kernel_times(reset=True)
+                    t0 = time.perf_counter()
+                eng.apply_lookup_table_dev(d_in.data_ptr(), d_idx.data_ptr(), d_out.data_ptr(), nb)
+            eng.synchronize()
+            dt = (time.perf_counter() - t0) / 5
+            ks_ms, br_ms, calls = eng.kernel_times(reset=True)
+            ok = bool(np.array_equal(ck.decrypt(d_out.cpu().numpy().view(np.uint64)), table[msgs]))
+            rec[f"batch_{nb}"] = {"pbs_per_s": nb / dt, "ms_per_step": dt * 1e3, "ms_per_256_lwes": dt * 1e3 * 256 / nb,
+                                  "kernel_ms": {"keyswitch": ks_ms / max(calls, 1), "blind_rotate": br_ms / max(calls, 1)},
+                                  "verified_decrypt": ok}
+        return rec
+    finally:
+        eng.close()
+
+
 def flop_per_cmux_step(P):
     """Algorithmic f64 FLOP of one CMUX step (SURVEY 8(d) "secondary"; ggsw.rs:477-598): l(k+1) forward +
     (k+1) inverse size-N/2 complex FFTs at 5 n log2 n, 8 FLOP per complex multiply-accumulate of the
@@ -830,6 +868,12 @@ def main():
             rec["multi_bit_pbs"] = bench_multi_bit(fhestr, local_rank, B, args.steps)
         except Exception as e:   # secondary section
             rec["multi_bit_pbs"] = {"error": f"{type(e).__name__}: {e}"}
+
+    if rank == 0 and world == 1 and not args.no_strings:
+        try:
+            rec["n1024_k2"] = bench_n1024_k2(fhestr, local_rank)
+        except Exception as e:   # secondary section
+            rec["n1024_k2"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0 and world == 1 and not args.no_p44:
         try:

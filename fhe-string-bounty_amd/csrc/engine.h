@@ -53,6 +53,7 @@ struct EngineEnv {
     int cluster_spin_limit = -1;      // FHESTR_CLUSTER_SPIN_LIMIT   polls before a hand-over wait gives up
     int multibit_combine_max = -1;    // FHESTR_MULTIBIT_COMBINE_MAX fhe_engine_set_multibit_combine_max at creation
     int cluster_test_fault = -1;      // FHESTR_CLUSTER_TEST_FAULT   honoured by the -DFHESTR_TEST_HOOKS build only
+    int dense_per_cu = -1;            // FHESTR_DENSE_PER_CU         LWEs per CU beyond which the dense wide kernel runs (0 = never)
     static EngineEnv read();
 };
 
@@ -79,6 +80,7 @@ struct Engine {
     static constexpr int OVL_MAX = 4;
     int ovl_streams = 2;
     uint32_t wide_fair_shift = 13;           // two-LWEs-per-CU kernel: log2 ticks (100 MHz) of the priority time slice, 0 = off (FHESTR_WIDE_FAIR)
+    uint32_t dense_per_cu = 2;               // N = 1024, k = 2: the four-workgroups-per-CU kernel beyond this many LWEs per CU (0 = never)
     bool keep_busy = false;                  // small launches carry replicas on the idle CUs (fhe_engine_set_keep_busy, FHESTR_KEEP_BUSY)
     hipStream_t ovl_stream[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ovl_done[OVL_MAX] = {nullptr, nullptr, nullptr, nullptr};

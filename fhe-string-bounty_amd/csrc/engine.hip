@@ -76,6 +76,9 @@ struct BrVariant {
     const void* xcd_fn = nullptr;
     int xcd_size = 0, xcd_threads = 0;
     size_t xcd_ws = 0, xcd_lds = 0, xcd_lds_one_per_cu = 0;
+    // wide layout, dense twin (BrWideCfg<..., DENSE>): four workgroups per CU, for batches beyond two LWEs per CU
+    const void* dense_fn = nullptr;
+    size_t dense_lds = 0;
 };
 
 template <int LOGN, int LOGR, int K1, int L>
@@ -101,6 +104,11 @@ BrVariant make_wide_variant() {
     v.threads = CFG::THREADS;
     v.lds_bytes = CFG::LDS_FIXED;
     v.rotate_fn = reinterpret_cast<const void*>(&blind_rotate_wide_kernel<LOGN, LOGR, K1, L>);
+    if constexpr (LOGN == 10 && K1 == 3) {       // N = 1024, k = 2: three polynomials per thread
+        using DC = BrWideCfg<LOGN, LOGR, K1, L, true>;
+        v.dense_fn = reinterpret_cast<const void*>(&blind_rotate_wide_kernel<LOGN, LOGR, K1, L, true>);
+        v.dense_lds = DC::LDS_FIXED;
+    }
     return v;
 }
 
@@ -288,6 +296,7 @@ EngineEnv EngineEnv::read() {
     auto num = [](const char* name, int& out) { if (const char* t = getenv(name)) out = atoi(t); };
     num("FHESTR_LOG2_POINTS", v.log2_points);
     num("FHESTR_WIDE_FAIR", v.wide_fair);
+    num("FHESTR_DENSE_PER_CU", v.dense_per_cu);
     num("FHESTR_KEEP_BUSY", v.keep_busy);
     num("FHESTR_OVERLAP_STREAMS", v.overlap_streams);
     num("FHESTR_KS_MFMA", v.ks_mfma);
@@ -315,6 +324,7 @@ int Engine::create(const fhe_params_t& p, int device, Engine** out) {
     e->variant_large = v;
     const EngineEnv env = EngineEnv::read();
     if (env.wide_fair >= 0) e->wide_fair_shift = (uint32_t)std::min(20, env.wide_fair);
+    if (env.dense_per_cu >= 0) e->dense_per_cu = (uint32_t)env.dense_per_cu;
     if (env.keep_busy >= 0) e->keep_busy = env.keep_busy != 0;
     if (env.overlap_streams >= 0) e->ovl_streams = std::min((int)Engine::OVL_MAX, std::max(2, env.overlap_streams));
     if (env.ks_mfma >= 0) e->ks_mfma_enabled = env.ks_mfma != 0;
@@ -918,6 +928,11 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
     // keep-busy mode (fhe_engine_set_keep_busy): a launch that would leave more than half of the CUs idle carries replicas of
     // its workgroups on them (they recompute and store nothing) -- the part then keeps its clock for the large launch that
     // follows (2.22 -> 2.39 GHz over 14 ms otherwise, profiles/r03_after_idle.txt), at the price of the energy
+    if (v->dense_fn && dense_per_cu && count > dense_per_cu * (uint32_t)cu_count) {       // more than two LWEs per CU: the variant that puts four on one
+        a.fair_shift = 0;
+        HIP_TRY(hipLaunchKernel(v->dense_fn, dim3(count), dim3(v->threads), args, v->dense_lds + (size_t)p.n * v->lds_per_n, stream));
+        return 0;
+    }
     uint32_t grid = count;
     if (keep_busy && !v->wide && !v->large && count * 2 <= (uint32_t)cu_count) grid = count * ((uint32_t)cu_count / count);
     HIP_TRY(hipLaunchKernel(v->rotate_fn, dim3(grid), dim3(v->threads), args,

@@ -22,5 +22,8 @@ if p:
 mb = d.get("multi_bit_pbs") or {}
 for g, v in mb.items():
     print(" ", g, round(v["pbs_per_s"]), "PBS/s; 1 LWE", round(v["batch_1"]["ms_per_step"], 3), "ms; eq", round(v["fhestring_eq_256_ms"], 2), "ms")
+for k, v in (d.get("n1024_k2") or {}).items():
+    if isinstance(v, dict):
+        print("  n1024_k2", k, round(v["pbs_per_s"]), "PBS/s;", round(v["ms_per_step"], 3), "ms per step;", round(v["ms_per_256_lwes"], 3), "ms per 256 LWEs; correct", v["verified_decrypt"])
 c = d.get("cpu_baseline") or {}
 print("cpu", c.get("value"), c.get("cores"), c.get("pbs_per_s_by_threads"))

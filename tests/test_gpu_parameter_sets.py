@@ -143,3 +143,50 @@ def test_device_keygen_is_bit_identical_to_the_oracle_keygen(name):
         assert np.array_equal(ksk, osk.ksk) and np.array_equal(bsk, osk.bsk)
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_dense_kernel_of_n1024_against_the_two_per_cu_kernel():
+    """N = 1024, k = 2 (PARAM_MESSAGE_2_CARRY_1_KS_PBS): beyond two LWEs per CU the engine takes the dense blind-rotation
+    kernel (one exchange-plane set, four workgroups per CU; pbs_kernels.hip.h BrWideCfg DENSE).  Same algorithm, another
+    order of the transforms' roundings: the 800 outputs of one call decrypt to the table and their PHASES sit within 8 sigma
+    of the difference of two PBS noises (noise model) of those of the same ciphertexts sent in calls of 400 (two-per-CU
+    kernel) -- the bar of the oracle test above.  Neither words nor noise samples can be compared between two kernels: one
+    rounding that moves one decomposition digit in one of the 742 steps adds a whole key row to the accumulator, a fresh
+    mask, and every later digit -- hence the noise sample -- differs (measured with scripts/dense_diff.py: every word
+    differs, phase distance median 2^48.6 = sigma, between the two older kernels as well)."""
+    import fhestr
+    import torch
+    from conftest import torus_distance
+    P = _params("PARAM_MESSAGE_2_CARRY_1_KS_PBS")
+    M = P.msg_mod * P.carry_mod
+    ck = fhestr.ClientKey(P, 0x5EA)
+    g, s = ck.secret_keys()
+    eng = fhestr.Engine(P, 0)
+    try:
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        eng.generate_keys(g, s, 0x5EA)
+        rng = np.random.default_rng(12)
+        table = rng.integers(0, M, size=M)
+        lut, _ = eng.generate_lookup_table(lambda x: int(table[x]))
+        B = 3 * cus + 32                       # three per CU and a ragged tail
+        half = B // 2
+        assert B > 2 * cus and cus < half <= 2 * cus
+        msgs = rng.integers(0, M, size=B)
+        cts = ck.encrypt(msgs)
+        idx = np.full(B, lut, dtype=np.uint32)
+        dense = eng.apply_lookup_table(cts, idx)
+        assert np.array_equal(ck.decrypt(dense), table[msgs])
+        halves = np.concatenate([eng.apply_lookup_table(cts[:half], idx[:half]), eng.apply_lookup_table(cts[half:], idx[half:])])
+        assert np.array_equal(ck.decrypt(halves), table[msgs])
+        big_sel = np.flatnonzero(g == 1)
+        phase = lambda cts: (cts[:, -1] - cts[:, big_sel].sum(axis=1, dtype=np.uint64))
+        with np.errstate(over="ignore"):
+            dist = torus_distance(phase(dense), phase(halves)).max()
+        tol = 8.0 * np.sqrt(2.0 * fhestr.noise_model(P)["v_pbs"]) * 2.0**64
+        print(f"dense vs two-per-CU kernel: max phase distance 2^{np.log2(dist + 1):.1f}, 8 sigma = 2^{np.log2(tol):.1f}")
+        assert dist < tol
+        small = eng.apply_lookup_table(cts[:64], idx[:64])
+        assert np.array_equal(ck.decrypt(small), table[msgs[:64]])
+    finally:
+        eng.close()
