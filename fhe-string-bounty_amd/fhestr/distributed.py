@@ -27,7 +27,10 @@ class ShardedPlanRunner:
         self.gathered_bytes = self.gathered_lwes * plan.params.big_size * 8
         self.collectives = sum(1 for lv in self.levels if lv["e_max"]) if world > 1 else 0
 
-    def run(self, inputs):
+    def run(self, inputs, device_outputs=False):
+        """inputs: host array or a tensor resident in HBM.  device_outputs=True (GpuBackend): the outputs stay in HBM too
+        (a torch int64 tensor [n_outputs][big_size], complete when this returns) -- a 1024-char string is 67 MB of
+        ciphertext, and a caller that feeds the next operation has no use for a host copy."""
         b = self.backend
         pool = b.alloc_pool(self.info["pool_slots"])
         b.load_inputs(pool, inputs, self.info["n_inputs"])
@@ -35,6 +38,8 @@ class ShardedPlanRunner:
             b.run_level(pool, l, self.rank)
             if self.world > 1 and lv["e_max"]:
                 b.all_gather(pool, lv["local_base"], lv["e_max"], lv["recv_base"], self.world)
+        if device_outputs:
+            return b.gather_outputs(pool, self.info["n_outputs"], to_host=False)
         return b.gather_outputs(pool, self.info["n_outputs"])
 
 
@@ -122,10 +127,14 @@ class GpuBackend:
         dist.all_gather_into_tensor(pool[recv_base: recv_base + e_max * world],
                                     pool[local_base: local_base + e_max], group=self.group)
 
-    def gather_outputs(self, pool, n_outputs):
+    def gather_outputs(self, pool, n_outputs, to_host=True):
         out = self.torch.empty((n_outputs, self.big), dtype=self.torch.int64, device=self.device)
         self.plan.gather_outputs_dev(pool.data_ptr(), out.data_ptr())
         stream = self.torch.cuda.current_stream(self.device)
+        if not to_host:
+            stream.synchronize()
+            self._check_engine()
+            return out
         if n_outputs * self.big * 8 < (4 << 20):
             stream.synchronize()
             self._check_engine()

@@ -242,8 +242,14 @@ def test_sharded_runner_gpu_backend_single_rank(toy_k1):
     try:
         backend = GpuBackend(plan, torch.device("cuda", 0))
         runner = ShardedPlanRunner(plan, 0, 1, backend)
-        got = _dec(toy_k1, runner.run(inputs))
+        host_out = runner.run(inputs)
+        got = _dec(toy_k1, host_out)
         assert np.array_equal(got, want) and got[0] == 1 and got[1] + 4 * got[2] == 2
+        # inputs and outputs resident in HBM: the same words as the host round trip
+        d_in = torch.from_numpy(inputs.view(np.int64)).cuda()
+        d_out = runner.run(d_in, device_outputs=True)
+        assert isinstance(d_out, torch.Tensor) and d_out.is_cuda
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint64), host_out)
         # exercise the collective itself on a level region
         pool = backend.alloc_pool(plan.info()["pool_slots"])
         lv = plan.level_info(0)
