@@ -106,6 +106,7 @@ struct Engine {
     size_t cap_ks_digits = 0;
     bool ks_mfma_enabled = true;      // FHESTR_KS_MFMA=0: byte-plane dot4 kernel everywhere
     double* d_fbsk = nullptr;
+    double* d_fbsk_dense = nullptr;          // the same key in the dense wide kernel's Fourier order (N = 1024, k = 2 only)
     uint64_t* d_luts = nullptr;
     size_t luts_cap = 0;
     uint32_t n_luts = 0;

@@ -19,6 +19,7 @@
 #include "lwe_kernels.hip.h"
 #include "ks_mfma_kernels.hip.h"
 #include "pbs_kernels.hip.h"
+#include "pbs_dense_kernels.hip.h"
 #include "pbs_large_kernels.hip.h"
 #include "pbs_cluster_kernels.hip.h"
 #include "pbs_xcd_kernels.hip.h"
@@ -76,9 +77,11 @@ struct BrVariant {
     const void* xcd_fn = nullptr;
     int xcd_size = 0, xcd_threads = 0;
     size_t xcd_ws = 0, xcd_lds = 0, xcd_lds_one_per_cu = 0;
-    // wide layout, dense twin (BrWideCfg<..., DENSE>): four workgroups per CU, for batches beyond two LWEs per CU
+    // dense layout (pbs_dense_kernels.hip.h): four workgroups per CU, for batches beyond two LWEs per CU
     const void* dense_fn = nullptr;
     size_t dense_lds = 0;
+    const void* dense_convert_fn = nullptr;     // its Fourier key is in its own plan's order: a second copy of the key
+    int dense_convert_threads = 0;
 };
 
 template <int LOGN, int LOGR, int K1, int L>
@@ -104,10 +107,13 @@ BrVariant make_wide_variant() {
     v.threads = CFG::THREADS;
     v.lds_bytes = CFG::LDS_FIXED;
     v.rotate_fn = reinterpret_cast<const void*>(&blind_rotate_wide_kernel<LOGN, LOGR, K1, L>);
-    if constexpr (LOGN == 10 && K1 == 3) {       // N = 1024, k = 2: three polynomials per thread
-        using DC = BrWideCfg<LOGN, LOGR, K1, L, true>;
-        v.dense_fn = reinterpret_cast<const void*>(&blind_rotate_wide_kernel<LOGN, LOGR, K1, L, true>);
+    if constexpr (LOGN == 10 && LOGR == 2 && K1 == 3 && L == 1) {       // N = 1024, k = 2 (pbs_dense_kernels.hip.h)
+        using DC = BrDenseCfg<LOGN, K1>;
+        static_assert(DC::THREADS == CFG::THREADS, "same launch shape as the wide kernel");
+        v.dense_fn = reinterpret_cast<const void*>(&blind_rotate_dense_kernel<LOGN, K1>);
         v.dense_lds = DC::LDS_FIXED;
+        v.dense_convert_fn = reinterpret_cast<const void*>(&bsk_convert_dense_kernel<LOGN, K1>);
+        v.dense_convert_threads = DC::THREADS;
     }
     return v;
 }
@@ -353,7 +359,7 @@ Engine::~Engine() {
     (void)hipSetDevice(device);
     if (stream) (void)sync_all_streams();
     auto rel = [](void* ptr) { if (ptr) (void)hipFree(ptr); };
-    rel(d_ksk_packed); rel(d_ksk_rowsum); rel(d_fbsk); rel(d_luts); rel(d_in); rel(d_small); rel(d_small2); rel(d_out); rel(d_idx);
+    rel(d_ksk_packed); rel(d_ksk_rowsum); rel(d_fbsk); rel(d_fbsk_dense); rel(d_luts); rel(d_in); rel(d_small); rel(d_small2); rel(d_out); rel(d_idx);
     rel(d_pool); rel(d_meta); rel(d_ws); rel(d_slot_exp); rel(d_cluster_ws); rel(d_cluster_ctl); rel(d_ksk_mfma); rel(d_ks_digits);
     for (int q = 0; q < OVL_MAX; q++) { rel(ovl_digits[q]); rel(ovl_small[q]); if (ovl_done[q]) (void)hipEventDestroy(ovl_done[q]); if (q >= 2 && ovl_stream[q]) (void)hipStreamDestroy(ovl_stream[q]); }
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -639,6 +645,14 @@ int Engine::install_keys(uint64_t* d_ksk_std, uint64_t* d_std) {
     }
     HIP_TRY(hipMalloc((void**)&d_fbsk, bsk_len * 8));   // N u64 -> N/2 c64: same byte count
     if (convert_polys(d_std, d_fbsk, (uint32_t)(bsk_len / p.N))) return 1;
+    if (d_fbsk_dense) { HIP_TRY(hipFree(d_fbsk_dense)); d_fbsk_dense = nullptr; }
+    if (variant_large->dense_convert_fn) {      // the dense kernel's own copy of the key (N = 1024, k = 2: 54.7 MB)
+        HIP_TRY(hipMalloc((void**)&d_fbsk_dense, bsk_len * 8));
+        uint32_t n_polys = (uint32_t)(bsk_len / p.N);
+        void* cargs[] = {(void*)&d_std, (void*)&d_fbsk_dense, (void*)&n_polys};
+        HIP_TRY(hipLaunchKernel(variant_large->dense_convert_fn, dim3(n_polys), dim3(variant_large->dense_convert_threads), cargs, 0, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
     if (variant->combine_generic_fn && probe_slot_exponents()) return 1;
     HIP_TRY(hipFuncSetAttribute(variant->rotate_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(variant->lds_bytes + (size_t)p.n * variant->lds_per_n)));
@@ -928,8 +942,9 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
     // keep-busy mode (fhe_engine_set_keep_busy): a launch that would leave more than half of the CUs idle carries replicas of
     // its workgroups on them (they recompute and store nothing) -- the part then keeps its clock for the large launch that
     // follows (2.22 -> 2.39 GHz over 14 ms otherwise, profiles/r03_after_idle.txt), at the price of the energy
-    if (v->dense_fn && dense_per_cu && count > dense_per_cu * (uint32_t)cu_count) {       // more than two LWEs per CU: the variant that puts four on one
+    if (v->dense_fn && d_fbsk_dense && dense_per_cu && count > dense_per_cu * (uint32_t)cu_count) {       // more than two LWEs per CU: the variant that puts four on one
         a.fair_shift = 0;
+        a.fbsk = d_fbsk_dense;
         HIP_TRY(hipLaunchKernel(v->dense_fn, dim3(count), dim3(v->threads), args, v->dense_lds + (size_t)p.n * v->lds_per_n, stream));
         return 0;
     }

@@ -171,6 +171,7 @@ struct FftPlan {
 // each other's combs, gives the inverse its own planes.
 struct FftSwap10 {
     static constexpr bool SWAP = true;
+    static constexpr int LOGW = 2;          // log2(waves per polynomial): the index bits that live in the wave number
     static constexpr int LOGP = 10;
     static constexpr int LOGR = 2;
     static constexpr int P = 1024;
@@ -186,6 +187,34 @@ struct FftSwap10 {
     // accumulator copy (N = 2048 coefficients) stored "transposed", slot = (j mod 4) * 512 + j / 4, so
     // that the rotation gather of a wave (coefficients 4 apart) reads consecutive slots
     __host__ __device__ static constexpr int acc_slot(int j) { return ((j & 3) << 9) | (j >> 2); }
+};
+
+// P = 512 points, 4 per thread, 128 threads (2 waves): the same scheme for N = 1024 (round 4: the dense kernel of the
+// k = 2 parameter sets, whose LDS pipe -- every inter-pass exchange and the twiddle table of the generic plan -- was
+// what bound it).  j = 128 m + 2 lane + wave; four radix-4 passes on (b8b7), (b6b5), (b4b3), (b2b1) with the two
+// register/lane swaps and the wave-local exchange of FftSwap10, then ONE radix-2 pass on b0 across the two waves:
+//   pass 4 -> k3, all four registers to the wave's slab rows (workgroup barrier)
+//   pass 5 -> k4: the thread of wave w takes rows r = 2w, 2w+1 of BOTH waves -- two butterflies, four outputs
+//             (regs (r & 1, k4) | wave r >> 1 | lane(5,4) k2 | lane(3..0) k0 k1)
+// Plane rows: 8 of 64 slots (wave w owns rows 4w..4w+3).  Used through fft_forward / fft_inverse only (one polynomial
+// at a time); the split kernel's spectrum hand-over is FftSwap10's.
+struct FftSwap9 {
+    static constexpr bool SWAP = true;
+    static constexpr int LOGW = 1;
+    static constexpr int LOGP = 9;
+    static constexpr int LOGR = 2;
+    static constexpr int P = 512;
+    static constexpr int R = 4;
+    static constexpr int T = 128;
+    static constexpr int FULL = 4;
+    static constexpr int LOGLAST = 1;
+    static constexpr int NP = 5;
+    static constexpr int NTW = 4;
+    __host__ __device__ static constexpr int log_radix(int s) { return s < 4 ? 2 : 1; }
+    __host__ __device__ static constexpr int log_S(int s) { return 9 - 2 * s; }
+    __host__ __device__ static constexpr int point(int tau, int m) { return 128 * m + 2 * (tau & 63) + (tau >> 6); }
+    // accumulator copy (N = 1024 coefficients): slot = (j mod 2) * 512 + j / 2 (a wave's gather reads consecutive slots)
+    __host__ __device__ static constexpr int acc_slot(int j) { return ((j & 1) << 9) | (j >> 1); }
 };
 
 // Plan used by the blind-rotation kernels for (log2 P, log2 R).
@@ -361,8 +390,13 @@ __device__ __forceinline__ void fft_init_consts(FftConsts<PL>& c, int tau) {
         const int lS1 = lS - PL::LOGR;
         int tp = tau & ((1 << lS1) - 1);
         if (PL::SWAP) {   // low index bits still to be transformed after pass s (see FftSwap10)
-            const int lane = tau & 63, w = tau >> 6;
-            tp = s == 0 ? ((lane << 2) | w) : s == 1 ? (((lane & 15) << 2) | w) : s == 2 ? (((lane >> 4) << 2) | w) : w;
+            const int lane = tau & 63;
+            int w = tau >> 6;
+            // FftSwap9, last twiddled pass: the angle depends on the wave number alone -- scalar registers (the dense
+            // kernel has none of the vector kind to spare)
+            if constexpr (PL::LOGP == 9) { if (s == 3) w = __builtin_amdgcn_readfirstlane(w); }
+            constexpr int LW = PL::SWAP ? (PL::LOGP - 8) : 0;       // FftSwap10: 2 wave bits, FftSwap9: 1
+            tp = s == 0 ? ((lane << LW) | w) : s == 1 ? (((lane & 15) << LW) | w) : s == 2 ? (((lane >> 4) << LW) | w) : w;
         }
 #pragma unroll
         for (int q = 0; q < PL::R; q++) {
@@ -460,7 +494,8 @@ __device__ __forceinline__ void swap10_twiddle(cplx* x, const cplx* tw) {
 // The head in three stages separated by the wave-local fences, so that callers carrying several
 // polynomials per thread can run stage by stage over all of them (one polynomial's LDS round trip
 // then hides behind the other's butterflies).
-__device__ __forceinline__ void swap10_fwd_stage1(cplx* x, const FftConsts<FftSwap10>& c, double* re, double* im, int tau) {
+template <class C>
+__device__ __forceinline__ void swap10_fwd_stage1(cplx* x, const C& c, double* re, double* im, int tau) {
     small_dft<4, false>(x);
     swap10_twiddle<false>(x, c.tw[0]);
     swap_regs_lanes(x);
@@ -474,7 +509,8 @@ __device__ __forceinline__ void swap10_fwd_stage1(cplx* x, const FftConsts<FftSw
         FHE_PIN_ORDER();
     }
 }
-__device__ __forceinline__ void swap10_fwd_stage2(cplx* x, const FftConsts<FftSwap10>& c, const double* re, const double* im, int tau) {
+template <class C>
+__device__ __forceinline__ void swap10_fwd_stage2(cplx* x, const C& c, const double* re, const double* im, int tau) {
 #pragma unroll
     for (int r = 0; r < 4; r++) { const int a = swap10_side_b(tau, r); x[r].re = re[a]; x[r].im = im[a]; }
     small_dft<4, false>(x);
@@ -482,7 +518,8 @@ __device__ __forceinline__ void swap10_fwd_stage2(cplx* x, const FftConsts<FftSw
     swap_regs_lanes(x);
     small_dft<4, false>(x);
 }
-__device__ __forceinline__ void swap10_fwd_stage3(cplx* x, const FftConsts<FftSwap10>& c, double* re, double* im, int tau) {
+template <class C>
+__device__ __forceinline__ void swap10_fwd_stage3(cplx* x, const C& c, double* re, double* im, int tau) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         if (r) x[r] = cmul(x[r], c.tw[3][r]);
@@ -490,7 +527,8 @@ __device__ __forceinline__ void swap10_fwd_stage3(cplx* x, const FftConsts<FftSw
         FHE_PIN_ORDER();
     }
 }
-__device__ __forceinline__ void swap10_forward_head(cplx* x, const FftConsts<FftSwap10>& c, double* re, double* im, int tau) {
+template <class C>
+__device__ __forceinline__ void swap10_forward_head(cplx* x, const C& c, double* re, double* im, int tau) {
     swap10_fwd_stage1(x, c, re, im, tau);
     wave_local_fence();
     swap10_fwd_stage2(x, c, re, im, tau);
@@ -509,7 +547,8 @@ __device__ __forceinline__ void swap10_inverse_head(const cplx* x, double* re, d
         FHE_PIN_ORDER();
     });
 }
-__device__ __forceinline__ void swap10_inv_stage1(cplx* x, const FftConsts<FftSwap10>& c, const double* re, const double* im, int tau) {
+template <class C>
+__device__ __forceinline__ void swap10_inv_stage1(cplx* x, const C& c, const double* re, const double* im, int tau) {
 #pragma unroll
     for (int r = 0; r < 4; r++) { const int a = swap10_slab(tau, r); x[r].re = re[a]; x[r].im = im[a]; }
     swap10_twiddle<true>(x, c.tw[3]);
@@ -523,7 +562,8 @@ __device__ __forceinline__ void swap10_inv_stage2(const cplx* x, double* re, dou
         FHE_PIN_ORDER();
     });
 }
-__device__ __forceinline__ void swap10_inv_stage3(cplx* x, const FftConsts<FftSwap10>& c, const double* re, const double* im, int tau) {
+template <class C>
+__device__ __forceinline__ void swap10_inv_stage3(cplx* x, const C& c, const double* re, const double* im, int tau) {
 #pragma unroll
     for (int r = 0; r < 4; r++) { const int a = swap10_side_a(tau, r); x[r].re = re[a]; x[r].im = im[a]; }
     swap10_twiddle<true>(x, c.tw[1]);
@@ -532,7 +572,8 @@ __device__ __forceinline__ void swap10_inv_stage3(cplx* x, const FftConsts<FftSw
     swap10_twiddle<true>(x, c.tw[0]);
     small_dft<4, true>(x);
 }
-__device__ __forceinline__ void swap10_inverse_tail(cplx* x, const FftConsts<FftSwap10>& c, double* re, double* im, int tau) {
+template <class C>
+__device__ __forceinline__ void swap10_inverse_tail(cplx* x, const C& c, double* re, double* im, int tau) {
     swap10_inv_stage1(x, c, re, im, tau);
     wave_local_fence();          // the exchange below reuses the slab rows just read
     swap10_inv_stage2(x, re, im, tau);
@@ -573,12 +614,51 @@ __device__ __forceinline__ void swap10_inverse(cplx (*x)[4], const FftConsts<Fft
     for (int p = 0; p < NPOLY; p++) swap10_inv_stage3(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
 }
 
+// FftSwap9: passes 1-4 and both in-wave exchanges are FftSwap10's stages (slab rows 4w + r, two waves); the pass across the
+// waves is a radix-2.
+__device__ __forceinline__ void swap9_forward(cplx* x, const FftConsts<FftSwap9>& c, double* re, double* im, int tau) {
+    swap10_fwd_stage1(x, c, re, im, tau);
+    wave_local_fence();
+    swap10_fwd_stage2(x, c, re, im, tau);
+    wave_local_fence();          // the slab stores below reuse the rows the exchange above read
+    swap10_fwd_stage3(x, c, re, im, tau);
+    __syncthreads();
+    const int lane = tau & 63, w = tau >> 6;
+#pragma unroll
+    for (int rl = 0; rl < 2; rl++) {
+        const int a0 = ((2 * w + rl) << 6) | lane, a1 = ((4 + 2 * w + rl) << 6) | lane;     // b0 = 0 / b0 = 1
+        const double ar = re[a0], ai = im[a0], br = re[a1], bi = im[a1];
+        x[2 * rl].re = ar + br; x[2 * rl].im = ai + bi;
+        x[2 * rl + 1].re = ar - br; x[2 * rl + 1].im = ai - bi;
+    }
+}
+__device__ __forceinline__ void swap9_inverse(cplx* x, const FftConsts<FftSwap9>& c, double* re, double* im, int tau) {
+    const int lane = tau & 63, w = tau >> 6;
+#pragma unroll
+    for (int rl = 0; rl < 2; rl++) {
+        const int a0 = ((2 * w + rl) << 6) | lane, a1 = ((4 + 2 * w + rl) << 6) | lane;
+        re[a0] = x[2 * rl].re + x[2 * rl + 1].re; im[a0] = x[2 * rl].im + x[2 * rl + 1].im;
+        FHE_PIN_ORDER();
+        re[a1] = x[2 * rl].re - x[2 * rl + 1].re; im[a1] = x[2 * rl].im - x[2 * rl + 1].im;
+        FHE_PIN_ORDER();
+    }
+    __syncthreads();
+    swap10_inv_stage1(x, c, re, im, tau);
+    wave_local_fence();          // the exchange below reuses the slab rows just read
+    swap10_inv_stage2(x, re, im, tau);
+    wave_local_fence();
+    swap10_inv_stage3(x, c, re, im, tau);
+}
+
 // Forward transform.  In: x[m] = point (tau + T*m) of the (already twisted) input.
 // Out: x[rho] in last-pass layout.  `re`/`im` are this group's LDS planes (P doubles each).
 template <class PL, class C>
 __device__ __forceinline__ void fft_forward(cplx* x, const C& c, double* re, double* im,
                                             int tau) {
-    if constexpr (PL::SWAP) {
+    if constexpr (PL::SWAP && PL::LOGP == 9) {
+        swap9_forward(x, c, re, im, tau);
+        return;
+    } else if constexpr (PL::SWAP) {
         swap10_forward<1>(reinterpret_cast<cplx(*)[4]>(x), c, re, 0, (int)(im - re), tau);
         return;
     }
@@ -630,7 +710,10 @@ __device__ __forceinline__ void fft_forward(cplx* x, const C& c, double* re, dou
 template <class PL, class C>
 __device__ __forceinline__ void fft_inverse(cplx* x, const C& c, double* re, double* im,
                                             int tau) {
-    if constexpr (PL::SWAP) {
+    if constexpr (PL::SWAP && PL::LOGP == 9) {
+        swap9_inverse(x, c, re, im, tau);
+        return;
+    } else if constexpr (PL::SWAP) {
         swap10_inverse<1>(reinterpret_cast<cplx(*)[4]>(x), c, re, 0, (int)(im - re), tau);
         return;
     }
@@ -744,6 +827,7 @@ __device__ __forceinline__ bool pass_sync_is_wave_local(int log_S_next) { return
 template <class PL, int NPOLY, class C>
 __device__ __forceinline__ void fft_forward_multi(cplx (*x)[PL::R], const C& c, double* re0,
                                                   int poly_stride, int im_off, int tau) {
+    static_assert(!PL::SWAP || PL::LOGP == 10, "several polynomials per thread: FftSwap10 only");
     if constexpr (PL::SWAP) {
         swap10_forward<NPOLY>(x, c, re0, poly_stride, im_off, tau);
         return;
@@ -776,6 +860,7 @@ __device__ __forceinline__ void fft_forward_multi(cplx (*x)[PL::R], const C& c, 
 template <class PL, int NPOLY, class C>
 __device__ __forceinline__ void fft_inverse_multi(cplx (*x)[PL::R], const C& c, double* re0,
                                                   int poly_stride, int im_off, int tau) {
+    static_assert(!PL::SWAP || PL::LOGP == 10, "several polynomials per thread: FftSwap10 only");
     if constexpr (PL::SWAP) {
         swap10_inverse<NPOLY>(x, c, re0, poly_stride, im_off, tau);
         return;

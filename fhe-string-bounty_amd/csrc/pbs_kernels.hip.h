@@ -163,10 +163,15 @@ __device__ __forceinline__ uint32_t acc_slot_of(uint32_t j) { return (uint32_t)P
 
 // Monomial rotation bookkeeping of one CMUX step: for the coefficient j = PL::point(tau, m) + h*P this
 // thread owns, where (acc * X^d)[j] = +-acc[(j - rem) mod N] sits in the LDS copy and whether it is
-// negated (polynomial_algorithms.rs:463-489; d = odd * N + rem).  The swap plan's thread owns
+// negated (polynomial_algorithms.rs:463-489; d = odd * N + rem).  (Written for FftSwap10's four waves; FftSwap9's two
+// waves are the same with 2 in place of 4 -- swap_wave_bits.)  The swap plan's thread owns
 // j = 4 q' + w (w = wave index) and stores coefficient 4 q + r at slot r * N/4 + q, so j - rem =
 // 4 (q' - rem/4 - [w < rem%4]) + ((w - rem) mod 4): everything but one add and one and-or per
 // coefficient is per-step or compile-time.
+template <class PL>
+__host__ __device__ constexpr int swap_wave_bits() {
+    if constexpr (PL::SWAP) return PL::LOGW; else return 0;
+}
 template <class PL, int LOGN>
 struct Rotation {
     int32_t oddmask;
@@ -177,12 +182,13 @@ struct Rotation {
         rem = d & ((1u << LOGN) - 1);
         oddmask = -(int32_t)((d >> LOGN) & 1);
         if constexpr (PL::SWAP) {
+            constexpr int LW = swap_wave_bits<PL>();      // FftSwap10: j = 4 q + w; FftSwap9: j = 2 q + w
             const int w = __builtin_amdgcn_readfirstlane(tau >> 6), lane = tau & 63;   // wave index: scalar
-            const int rr = (int)(rem & 3);
+            const int rr = (int)(rem & ((1u << LW) - 1));
             // the sign of q = lane - rem/4 - borrow + const says "wrapped around"; adding 2^31 flips it when
             // the whole polynomial is negated as well, so one arithmetic shift yields the negation mask
-            qb8 = (int32_t)((uint32_t)((lane - (int)(rem >> 2) - (w < rr ? 1 : 0)) << 3) + ((uint32_t)oddmask & 0x80000000u));
-            rbits8 = (uint32_t)((w - rr) & 3) << (LOGN - 2 + 3);
+            qb8 = (int32_t)((uint32_t)((lane - (int)(rem >> LW) - (w < rr ? 1 : 0)) << 3) + ((uint32_t)oddmask & 0x80000000u));
+            rbits8 = (uint32_t)((w - rr) & ((1 << LW) - 1)) << (LOGN - LW + 3);
         } else {
             qb8 = 0; rbits8 = 0;
         }
@@ -198,9 +204,10 @@ struct Rotation {
     // three instructions per coefficient -- add, and-or, arithmetic shift)
     // `row_base` = the copy's base address | rbits8 (scalar, formed once per step by the caller)
     __device__ __forceinline__ void source_bytes(int m, int h, uint32_t row_base, uint32_t& address, uint32_t& neg) const {
-        const int32_t q8 = qb8 + ((PL::point(0, m) + h * PL::P) / 4) * 8;
+        constexpr int LW = swap_wave_bits<PL>();
+        const int32_t q8 = qb8 + ((PL::point(0, m) + h * PL::P) >> LW) * 8;
         neg = (uint32_t)(q8 >> 31);
-        address = ((uint32_t)q8 & (((1u << (LOGN - 2)) - 1) << 3)) | row_base;       // v_and_or_b32
+        address = ((uint32_t)q8 & (((1u << (LOGN - LW)) - 1) << 3)) | row_base;       // v_and_or_b32
     }
 };
 
@@ -611,7 +618,7 @@ blind_rotate_kernel(BlindRotateArgs args) {
 // k+1 independent FFT streams to overlap LDS round trips with butterflies, and the smaller
 // footprint (accumulator copy + exchange planes) lets two LWEs share a CU for batches >= 512.
 // Barriers per CMUX step: forward exchange 0->1, inverse exchange 1->0, accumulator publish.
-template <int LOGN, int LOGR, int K1, int L, bool DENSE = false>
+template <int LOGN, int LOGR, int K1, int L>
 struct BrWideCfg {
     static constexpr int N = 1 << LOGN;
     static constexpr int P = N / 2;
@@ -621,35 +628,25 @@ struct BrWideCfg {
     static constexpr int THREADS = T;
     static constexpr int PLANE = P + 2;
     static constexpr int GROUP_SLOTS = 2 * P + 4;
-    // DENSE (round 4; N = 1024 with k = 2, PARAM_MESSAGE_2_CARRY_1 ...: three polynomials per thread).  With a plane set per
-    // polynomial and every twiddle in VGPRs that kernel needs more than 256 registers and 52 KB of LDS per 128-thread workgroup:
-    // one wave per SIMD, two workgroups per CU, 104.7 k PBS/s however large the batch.  The dense variant has ONE set of
-    // exchange planes -- the polynomials are transformed one after the other, a workgroup barrier between them -- keeps only
-    // pass 0's twiddles in VGPRs and is capped at 256 registers: four workgroups per CU (36 KB each), two waves on every SIMD,
-    // 131-135 k PBS/s from 1,024 LWEs.  A workgroup alone on its SIMDs is slower than the plain variant's (512 LWEs: 5.8 against
-    // 4.9 ms), so the host takes it only beyond two LWEs per CU, and without the priority slices (made for two workgroups per CU).
-    static constexpr bool SHARE_PLANES = DENSE;
-    static_assert(!DENSE || !PL::SWAP, "dense variant: generic plans only");
-    static constexpr int MIN_WAVES = SHARE_PLANES ? 2 : 1;       // per SIMD (__launch_bounds__' second argument)
     // plans with more than four passes keep only pass 0's twiddles in VGPRs (FftHybridConsts)
-    static constexpr bool TW_IN_LDS = !PL::SWAP && (PL::NTW > 4 || SHARE_PLANES);
+    static constexpr bool TW_IN_LDS = !PL::SWAP && PL::NTW > 4;
     static constexpr size_t LDS_TW = TW_IN_LDS ? (size_t)FftHybridConsts<PL>::ENTRIES * 16 : 0;
-    static constexpr size_t LDS_FIXED = (size_t)K1 * N * 8 /*acc*/ + (size_t)(SHARE_PLANES ? 1 : K1) * GROUP_SLOTS * 8 /*x*/ + LDS_TW;
+    static constexpr size_t LDS_FIXED = (size_t)K1 * N * 8 /*acc*/ + (size_t)K1 * GROUP_SLOTS * 8 /*x*/ + LDS_TW;
     // keep the whole Fourier GGSW of a step in VGPRs only when it is small
     // (also where the twiddles moved to LDS: without the prefetch N = 4096 has no spills but runs 9.5 instead of 7.8 ms)
     static constexpr bool PREFETCH_ALL = K1 * K1 * R * 4 <= 64;
 };
 
-template <int LOGN, int LOGR, int K1, int L, bool DENSE = false>
-__global__ void __launch_bounds__((BrWideCfg<LOGN, LOGR, K1, L, DENSE>::THREADS), (BrWideCfg<LOGN, LOGR, K1, L, DENSE>::MIN_WAVES))
+template <int LOGN, int LOGR, int K1, int L>
+__global__ void __launch_bounds__((BrWideCfg<LOGN, LOGR, K1, L>::THREADS))
 blind_rotate_wide_kernel(BlindRotateArgs args) {
-    using CFG = BrWideCfg<LOGN, LOGR, K1, L, DENSE>;
+    using CFG = BrWideCfg<LOGN, LOGR, K1, L>;
     using PL = typename CFG::PL;
     constexpr int N = CFG::N, P = CFG::P, R = CFG::R, T = CFG::T;
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t* lds_acc = reinterpret_cast<uint64_t*>(smem);                       // [K1][N]
     double* lds_x = reinterpret_cast<double*>(smem + (size_t)K1 * N * 8);        // [K1][GROUP_SLOTS]
-    double2* lds_tw = reinterpret_cast<double2*>(lds_x + (size_t)(CFG::SHARE_PLANES ? 1 : K1) * CFG::GROUP_SLOTS);    // [LDS_TW / 16]
+    double2* lds_tw = reinterpret_cast<double2*>(lds_x + (size_t)K1 * CFG::GROUP_SLOTS);    // [LDS_TW / 16]
     uint32_t* lds_d = reinterpret_cast<uint32_t*>(lds_tw + CFG::LDS_TW / 16);               // [n]
 
     const int tau = threadIdx.x;
@@ -801,15 +798,7 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
                     z.im = (double)decomp_next_digit(st_hi[p][m], args.base_log);
                     x[p][m] = cmul(z, twist[m]);
                 }
-            if constexpr (CFG::SHARE_PLANES) {
-#pragma unroll
-                for (int p = 0; p < K1; p++) {
-                    fft_forward<PL>(x[p], fc, lds_x, lds_x + CFG::PLANE, tau);
-                    __syncthreads();          // the next polynomial's pass-0 stores vs the other waves' reads of this one's
-                }
-            } else {
-                fft_forward_multi<PL, K1>(x, fc, lds_x, CFG::GROUP_SLOTS, CFG::PLANE, tau);
-            }
+            fft_forward_multi<PL, K1>(x, fc, lds_x, CFG::GROUP_SLOTS, CFG::PLANE, tau);
             const double2* bk = bk0 + (size_t)lvl_idx * K1 * K1 * P;
 #pragma unroll
             for (int row = 0; row < K1; row++)
@@ -832,15 +821,7 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
             if (it + 1 < L) __syncthreads();   // next level's pass-0 writes vs this level's last reads
         }
 
-        if constexpr (CFG::SHARE_PLANES) {
-#pragma unroll
-            for (int p = 0; p < K1; p++) {
-                fft_inverse<PL>(outf[p], fc, lds_x, lds_x + CFG::PLANE, tau);
-                if (p + 1 < K1) __syncthreads();
-            }
-        } else {
-            fft_inverse_multi<PL, K1>(outf, fc, lds_x, CFG::GROUP_SLOTS, CFG::PLANE, tau);
-        }
+        fft_inverse_multi<PL, K1>(outf, fc, lds_x, CFG::GROUP_SLOTS, CFG::PLANE, tau);
 #pragma unroll
         for (int p = 0; p < K1; p++)
 #pragma unroll
