@@ -1,5 +1,5 @@
 """Soak of the N = 1024 (k = 2) kernels: random batch sizes across the three layouts (one LWE per CU up to 256, two per CU
-up to 512, the dense four-per-CU kernel beyond), 16 random tables, fresh ciphertexts, every output decrypted.
+up to 512, the dense four-per-CU kernel (pbs_dense_kernels.hip.h) beyond), 16 random tables, fresh ciphertexts, every output decrypted.
 
     python3 scripts/soak_n1024.py [launches]      (default 80; GPU box)"""
 import sys

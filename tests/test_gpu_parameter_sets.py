@@ -148,7 +148,7 @@ def test_device_keygen_is_bit_identical_to_the_oracle_keygen(name):
 @pytest.mark.gpu
 def test_dense_kernel_of_n1024_against_the_two_per_cu_kernel():
     """N = 1024, k = 2 (PARAM_MESSAGE_2_CARRY_1_KS_PBS): beyond two LWEs per CU the engine takes the dense blind-rotation
-    kernel (one exchange-plane set, four workgroups per CU; pbs_kernels.hip.h BrWideCfg DENSE).  Same algorithm, another
+    kernel (one exchange-plane set, four workgroups per CU, FftSwap9; pbs_dense_kernels.hip.h).  Same algorithm, another
     order of the transforms' roundings: the 800 outputs of one call decrypt to the table and their PHASES sit within 8 sigma
     of the difference of two PBS noises (noise model) of those of the same ciphertexts sent in calls of 400 (two-per-CU
     kernel) -- the bar of the oracle test above.  Neither words nor noise samples can be compared between two kernels: one
