@@ -632,6 +632,13 @@ struct BrWideCfg {
     static constexpr bool TW_IN_LDS = !PL::SWAP && PL::NTW > 4;
     static constexpr size_t LDS_TW = TW_IN_LDS ? (size_t)FftHybridConsts<PL>::ENTRIES * 16 : 0;
     static constexpr size_t LDS_FIXED = (size_t)K1 * N * 8 /*acc*/ + (size_t)K1 * GROUP_SLOTS * 8 /*x*/ + LDS_TW;
+    // N >= 4096: the accumulator lives in its LDS copy only -- a thread re-reads its own 2 K1 R coefficients at the gather and
+    // at the update (the dense kernel's arrangement, pbs_dense_kernels.hip.h) instead of holding them in 4 K1 R VGPRs next to
+    // 256 registers' worth of transform state (47 / 67 spilled dwords with one / two levels before)
+#ifndef FHESTR_WIDE_ACC_LDS_LOGN
+#define FHESTR_WIDE_ACC_LDS_LOGN 12
+#endif
+    static constexpr bool ACC_IN_LDS = LOGN >= FHESTR_WIDE_ACC_LDS_LOGN;
     // keep the whole Fourier GGSW of a step in VGPRs only when it is small
     // (also where the twiddles moved to LDS: without the prefetch N = 4096 has no spills but runs 9.5 instead of 7.8 ms)
     static constexpr bool PREFETCH_ALL = K1 * K1 * R * 4 <= 64;
@@ -694,7 +701,9 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
         twbias[m].im = cb * (cs + sn);
     }
 
-    uint64_t acc_lo[K1][R], acc_hi[K1][R];
+    constexpr bool ACC_LDS = CFG::ACC_IN_LDS;
+    uint64_t acc_lo[ACC_LDS ? 1 : K1][R], acc_hi[ACC_LDS ? 1 : K1][R];
+    auto own_slot = [&](int p, int m, int h) { return (size_t)p * N + acc_slot_of<PL>(PL::point(tau, m) + h * P); };
     {
         const uint32_t d = modulus_switch(lwe[n], LOGN);
         const uint32_t rem = d & (N - 1);
@@ -710,7 +719,7 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
                     const bool neg = ((j + rem) >= (uint32_t)N) != odd;
                     uint64_t v = lut[(size_t)p * N + src];
                     v = neg ? (0 - v) : v;
-                    if (h == 0) acc_lo[p][m] = v; else acc_hi[p][m] = v;
+                    if constexpr (!ACC_LDS) { if (h == 0) acc_lo[p][m] = v; else acc_hi[p][m] = v; }
                     lds_acc[(size_t)p * N + acc_slot_of<PL>(j)] = v;
                 }
     }
@@ -778,7 +787,9 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
                     }
                     const uint64_t sm = ((uint64_t)sm32 << 32) | sm32;
                     const uint64_t v = (gathered ^ sm) - sm;
-                    const uint64_t own = h == 0 ? acc_lo[p][m] : acc_hi[p][m];
+                    uint64_t own;
+                    if constexpr (ACC_LDS) own = lds_acc[own_slot(p, m, h)];
+                    else own = h == 0 ? acc_lo[p][m] : acc_hi[p][m];
                     const uint32_t st = L == 1 ? decomp_single_biased(v - own, bL, dbias) : decomp_init_state(v - own, bL);
                     if (h == 0) st_lo[p][m] = st; else st_hi[p][m] = st;
                 }
@@ -827,10 +838,15 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
 #pragma unroll
             for (int m = 0; m < R; m++) {
                 cplx t = cmul_conj(outf[p][m], twist[m]);
+                if constexpr (ACC_LDS) {
+                    lds_acc[own_slot(p, m, 0)] += from_torus(t.re);
+                    lds_acc[own_slot(p, m, 1)] += from_torus(t.im);
+                } else {
                 acc_lo[p][m] += from_torus(t.re);
                 acc_hi[p][m] += from_torus(t.im);
                 lds_acc[(size_t)p * N + acc_slot_of<PL>(PL::point(tau, m))] = acc_lo[p][m];
                 lds_acc[(size_t)p * N + acc_slot_of<PL>(PL::point(tau, m) + P)] = acc_hi[p][m];
+                }
                 FHE_PIN_ORDER();
             }
         __syncthreads();
@@ -850,7 +866,9 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const uint32_t j = PL::point(tau, m) + h * P;
-                const uint64_t v = h == 0 ? acc_lo[p][m] : acc_hi[p][m];
+                uint64_t v;
+                if constexpr (ACC_LDS) v = lds_acc[own_slot(p, m, h)];
+                else v = h == 0 ? acc_lo[p][m] : acc_hi[p][m];
                 if (p == K1 - 1) {
                     if (j == 0) out[(size_t)(K1 - 1) * N] = v;
                 } else {

@@ -146,7 +146,7 @@ def test_device_keygen_is_bit_identical_to_the_oracle_keygen(name):
 
 
 @pytest.mark.gpu
-def test_dense_kernel_of_n1024_against_the_two_per_cu_kernel():
+def test_dense_kernel_of_n1024_against_the_oracle_and_the_two_per_cu_kernel():
     """N = 1024, k = 2 (PARAM_MESSAGE_2_CARRY_1_KS_PBS): beyond two LWEs per CU the engine takes the dense blind-rotation
     kernel (one exchange-plane set, four workgroups per CU, FftSwap9; pbs_dense_kernels.hip.h).  Same algorithm, another
     order of the transforms' roundings: the 800 outputs of one call decrypt to the table and their PHASES sit within 8 sigma
@@ -154,9 +154,12 @@ def test_dense_kernel_of_n1024_against_the_two_per_cu_kernel():
     kernel) -- the bar of the oracle test above.  Neither words nor noise samples can be compared between two kernels: one
     rounding that moves one decomposition digit in one of the 742 steps adds a whole key row to the accumulator, a fresh
     mask, and every later digit -- hence the noise sample -- differs (measured with scripts/dense_diff.py: every word
-    differs, phase distance median 2^48.6 = sigma, between the two older kernels as well)."""
+    differs, phase distance median 2^48.6 = sigma, between the two older kernels as well).
+    The CPU oracle, handed the exported device keys, bootstraps eight of the 800 ciphertexts (the first and last of the
+    launch among them): same messages, phases within the same bar of the dense kernel's."""
     import fhestr
     import torch
+    import oracle as O
     from conftest import torus_distance
     P = _params("PARAM_MESSAGE_2_CARRY_1_KS_PBS")
     M = P.msg_mod * P.carry_mod
@@ -165,7 +168,7 @@ def test_dense_kernel_of_n1024_against_the_two_per_cu_kernel():
     eng = fhestr.Engine(P, 0)
     try:
         cus = torch.cuda.get_device_properties(0).multi_processor_count
-        eng.generate_keys(g, s, 0x5EA)
+        bsk, ksk = eng.generate_keys(g, s, 0x5EA, export=True)
         rng = np.random.default_rng(12)
         table = rng.integers(0, M, size=M)
         lut, _ = eng.generate_lookup_table(lambda x: int(table[x]))
@@ -188,5 +191,15 @@ def test_dense_kernel_of_n1024_against_the_two_per_cu_kernel():
         assert dist < tol
         small = eng.apply_lookup_table(cts[:64], idx[:64])
         assert np.array_equal(ck.decrypt(small), table[msgs[:64]])
+        # the oracle on the same keys and ciphertexts
+        osk = O.ServerKey.from_keys(_oracle_params(P), bsk, ksk, threads=8)
+        olut, _ = osk.generate_lookup_table(lambda x: int(table[x]))
+        pick = np.array([0, 1, cus, 2 * cus + 1, 3 * cus - 1, 3 * cus, B - 2, B - 1])
+        want = osk.apply_lookup_table_batch(cts[pick], olut, threads=8)
+        assert np.array_equal(ck.decrypt(want), table[msgs[pick]])
+        with np.errstate(over="ignore"):
+            odist = torus_distance(phase(dense[pick]), phase(want)).max()
+        print(f"dense kernel vs oracle: max phase distance 2^{np.log2(odist + 1):.1f}")
+        assert odist < tol
     finally:
         eng.close()
