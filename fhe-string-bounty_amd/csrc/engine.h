@@ -12,7 +12,7 @@
 
 // bumped whenever a device kernel changes; profiles/r03_counters.json records the revision its
 // rocprofv3 counters were taken on and bench.py only attaches them to a matching build
-#define FHESTR_KERNEL_REVISION "r04.0"
+#define FHESTR_KERNEL_REVISION "r04.1"
 
 namespace fhe {
 

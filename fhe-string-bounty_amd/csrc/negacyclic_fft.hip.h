@@ -482,6 +482,37 @@ __device__ __forceinline__ void dft4_emit(const cplx* x, Emit emit) {
     if (!INV) { y.re = d0.re - d1.im; y.im = d0.im + d1.re; } else { y.re = d0.re + d1.im; y.im = d0.im - d1.re; }
     emit(3, y);
 }
+// Inverse pass with its twiddles folded in: y = IDFT4(x0, x1 conj(w1), x2 conj(w2), x3 conj(w3)) in natural order.  The
+// difference of a butterfly whose second operand is a product, a - w b, is taken as 2 a - (a + w b): the sum costs the four
+// multiply-adds the product alone would, the difference two -- 24 f64 instructions instead of 12 (three products) + 16
+// (butterflies); 32 of the ~1,290 instructions of a P22 CMUX step.  emit(q, y) as in dft4_emit (order 0, 2, 1, 3).
+template <class Emit>
+__device__ __forceinline__ void idft4_twiddled_emit(const cplx* x, const cplx* tw, Emit emit) {
+    cplx t1, u0, u1, d0, d1, y;
+    u0.re = fma(x[2].re, tw[2].re, fma(x[2].im, tw[2].im, x[0].re));
+    u0.im = fma(x[2].im, tw[2].re, fma(-x[2].re, tw[2].im, x[0].im));
+    d0.re = fma(2.0, x[0].re, -u0.re);
+    d0.im = fma(2.0, x[0].im, -u0.im);
+    t1 = cmul_conj(x[1], tw[1]);
+    u1.re = fma(x[3].re, tw[3].re, fma(x[3].im, tw[3].im, t1.re));
+    u1.im = fma(x[3].im, tw[3].re, fma(-x[3].re, tw[3].im, t1.im));
+    d1.re = fma(2.0, t1.re, -u1.re);
+    d1.im = fma(2.0, t1.im, -u1.im);
+    y.re = u0.re + u1.re; y.im = u0.im + u1.im; emit(0, y);
+    y.re = u0.re - u1.re; y.im = u0.im - u1.im; emit(2, y);
+    y.re = d0.re - d1.im; y.im = d0.im + d1.re; emit(1, y);      // d1 * (+i)
+    y.re = d0.re + d1.im; y.im = d0.im - d1.re; emit(3, y);
+}
+__device__ __forceinline__ void idft4_twiddled(cplx* x, const cplx* tw) {
+    cplx y[4];
+    idft4_twiddled_emit(x, tw, [&](int q, cplx v) { y[q] = v; });
+#pragma unroll
+    for (int q = 0; q < 4; q++) x[q] = y[q];
+}
+#ifndef FHESTR_FUSED_IDFT
+#define FHESTR_FUSED_IDFT 1
+#endif
+
 template <bool INV>
 __device__ __forceinline__ void swap10_twiddle(cplx* x, const cplx* tw) {
 #pragma unroll
@@ -551,21 +582,35 @@ template <class C>
 __device__ __forceinline__ void swap10_inv_stage1(cplx* x, const C& c, const double* re, const double* im, int tau) {
 #pragma unroll
     for (int r = 0; r < 4; r++) { const int a = swap10_slab(tau, r); x[r].re = re[a]; x[r].im = im[a]; }
+    if (FHESTR_FUSED_IDFT) {
+        idft4_twiddled(x, c.tw[3]);
+        swap_regs_lanes(x);           // the twiddles of the next pass (c.tw[2]) are folded into stage 2's butterfly
+        return;
+    }
     swap10_twiddle<true>(x, c.tw[3]);
     small_dft<4, true>(x);
     swap_regs_lanes(x);
     swap10_twiddle<true>(x, c.tw[2]);
 }
-__device__ __forceinline__ void swap10_inv_stage2(const cplx* x, double* re, double* im, int tau) {
-    dft4_emit<true>(x, [&](int r, cplx y) {
+template <class C>
+__device__ __forceinline__ void swap10_inv_stage2(const cplx* x, const C& c, double* re, double* im, int tau) {
+    auto store = [&](int r, cplx y) {
         const int a = swap10_side_b(tau, r); re[a] = y.re; im[a] = y.im;
         FHE_PIN_ORDER();
-    });
+    };
+    if (FHESTR_FUSED_IDFT) idft4_twiddled_emit(x, c.tw[2], store);
+    else dft4_emit<true>(x, store);
 }
 template <class C>
 __device__ __forceinline__ void swap10_inv_stage3(cplx* x, const C& c, const double* re, const double* im, int tau) {
 #pragma unroll
     for (int r = 0; r < 4; r++) { const int a = swap10_side_a(tau, r); x[r].re = re[a]; x[r].im = im[a]; }
+    if (FHESTR_FUSED_IDFT) {
+        idft4_twiddled(x, c.tw[1]);
+        swap_regs_lanes(x);
+        idft4_twiddled(x, c.tw[0]);
+        return;
+    }
     swap10_twiddle<true>(x, c.tw[1]);
     small_dft<4, true>(x);
     swap_regs_lanes(x);
@@ -576,7 +621,7 @@ template <class C>
 __device__ __forceinline__ void swap10_inverse_tail(cplx* x, const C& c, double* re, double* im, int tau) {
     swap10_inv_stage1(x, c, re, im, tau);
     wave_local_fence();          // the exchange below reuses the slab rows just read
-    swap10_inv_stage2(x, re, im, tau);
+    swap10_inv_stage2(x, c, re, im, tau);
     wave_local_fence();
     swap10_inv_stage3(x, c, re, im, tau);
 }
@@ -608,7 +653,7 @@ __device__ __forceinline__ void swap10_inverse(cplx (*x)[4], const FftConsts<Fft
     for (int p = 0; p < NPOLY; p++) swap10_inv_stage1(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
     wave_local_fence();
 #pragma unroll
-    for (int p = 0; p < NPOLY; p++) swap10_inv_stage2(x[p], re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    for (int p = 0; p < NPOLY; p++) swap10_inv_stage2(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
     wave_local_fence();
 #pragma unroll
     for (int p = 0; p < NPOLY; p++) swap10_inv_stage3(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
@@ -645,7 +690,7 @@ __device__ __forceinline__ void swap9_inverse(cplx* x, const FftConsts<FftSwap9>
     __syncthreads();
     swap10_inv_stage1(x, c, re, im, tau);
     wave_local_fence();          // the exchange below reuses the slab rows just read
-    swap10_inv_stage2(x, re, im, tau);
+    swap10_inv_stage2(x, c, re, im, tau);
     wave_local_fence();
     swap10_inv_stage3(x, c, re, im, tau);
 }
@@ -736,6 +781,12 @@ __device__ __forceinline__ void fft_inverse(cplx* x, const C& c, double* re, dou
                 }
             }
         }
+        if (FHESTR_FUSED_IDFT && R == 4 && s < PL::NTW && lr == PL::LOGR) {      // twiddles folded into the butterflies
+            cplx tw[4];
+#pragma unroll
+            for (int q = 1; q < 4; q++) tw[q] = c.get(s, q);
+            idft4_twiddled(x, tw);
+        } else {
         if (s < PL::NTW) {
 #pragma unroll
             for (int q = 1; q < R; q++) x[q] = cmul_conj(x[q], c.get(s, q));
@@ -745,6 +796,7 @@ __device__ __forceinline__ void fft_inverse(cplx* x, const C& c, double* re, dou
         } else {
 #pragma unroll
             for (int gi = 0; gi < groups; gi++) small_dft<(1 << PL::LOGLAST), true>(x + gi * rr);
+        }
         }
         if (s > 0) {
 #pragma unroll
@@ -803,6 +855,13 @@ __device__ __forceinline__ void pass_compute(cplx* x, int s, const C& c) {
     constexpr int R = PL::R;
     const int lr = PL::log_radix(s);
     const int rr = 1 << lr;
+    if (FHESTR_FUSED_IDFT && INV && R == 4 && s < PL::NTW && lr == PL::LOGR) {      // twiddles folded into the butterflies
+        cplx tw[4];
+#pragma unroll
+        for (int q = 1; q < 4; q++) tw[q] = c.get(s, q);
+        idft4_twiddled(x, tw);
+        return;
+    }
     if (INV && s < PL::NTW) {
 #pragma unroll
         for (int q = 1; q < R; q++) x[q] = cmul_conj(x[q], c.get(s, q));
