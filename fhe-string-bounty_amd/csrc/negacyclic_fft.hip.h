@@ -659,6 +659,11 @@ __device__ __forceinline__ void swap10_inverse(cplx (*x)[4], const FftConsts<Fft
     for (int p = 0; p < NPOLY; p++) swap10_inv_stage3(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
 }
 
+#ifdef FHESTR_ABLATE_DENSE_BARRIERS      // timing experiment only (wrong results): where does the dense kernel's time go?
+#define FHE_DENSE_SYNC() do {} while (0)
+#else
+#define FHE_DENSE_SYNC() __syncthreads()
+#endif
 // FftSwap9: passes 1-4 and both in-wave exchanges are FftSwap10's stages (slab rows 4w + r, two waves); the pass across the
 // waves is a radix-2.
 __device__ __forceinline__ void swap9_forward(cplx* x, const FftConsts<FftSwap9>& c, double* re, double* im, int tau) {
@@ -667,7 +672,7 @@ __device__ __forceinline__ void swap9_forward(cplx* x, const FftConsts<FftSwap9>
     swap10_fwd_stage2(x, c, re, im, tau);
     wave_local_fence();          // the slab stores below reuse the rows the exchange above read
     swap10_fwd_stage3(x, c, re, im, tau);
-    __syncthreads();
+    FHE_DENSE_SYNC();
     const int lane = tau & 63, w = tau >> 6;
 #pragma unroll
     for (int rl = 0; rl < 2; rl++) {
@@ -687,7 +692,7 @@ __device__ __forceinline__ void swap9_inverse(cplx* x, const FftConsts<FftSwap9>
         re[a1] = x[2 * rl].re - x[2 * rl + 1].re; im[a1] = x[2 * rl].im - x[2 * rl + 1].im;
         FHE_PIN_ORDER();
     }
-    __syncthreads();
+    FHE_DENSE_SYNC();
     swap10_inv_stage1(x, c, re, im, tau);
     wave_local_fence();          // the exchange below reuses the slab rows just read
     swap10_inv_stage2(x, c, re, im, tau);

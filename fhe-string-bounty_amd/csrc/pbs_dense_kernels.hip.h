@@ -119,7 +119,11 @@ blind_rotate_dense_kernel(BlindRotateArgs args) {
             for (int col = 0; col < K1; col++)
 #pragma unroll
                 for (int rho = 0; rho < R; rho++)
+#ifdef FHESTR_ABLATE_DENSE_KEY
+                    brow[col][rho] = make_double2(1.0 + row + col, 0.5 + rho + (double)i);
+#else
                     brow[col][rho] = key_load(key_rsrc, key_off, (uint32_t)((i * GGSW_ELEMS + ((size_t)row * K1 + col) * P + rho * T) * 16));
+#endif
         };
         if (ROW_PREFETCH) request_row(0);
 
@@ -137,7 +141,11 @@ blind_rotate_dense_kernel(BlindRotateArgs args) {
                 for (int h = 0; h < 2; h++) {
                     uint32_t address, sm32;
                     rot.source_bytes(m, h, row_base, address, sm32);
+#ifdef FHESTR_ABLATE_DENSE_GATHER
+                    const uint64_t gathered = (uint64_t)address * 0x9E3779B97F4A7C15ull;
+#else
                     const uint64_t gathered = lds_load_u64(address);
+#endif
                     const uint64_t sm = ((uint64_t)sm32 << 32) | sm32;
                     const uint64_t v = (gathered ^ sm) - sm;
                     st[h] = decomp_single_biased(v - own[own_slot(row, m, h)], bL, dbias);
@@ -146,7 +154,7 @@ blind_rotate_dense_kernel(BlindRotateArgs args) {
             }
             fft_forward<PL>(xr, fc, lds_x, lds_x + CFG::PLANE, tau);
             if (!ROW_PREFETCH) request_row(row);
-            __syncthreads();          // the next polynomial's first stores vs the other wave's reads of this one's last pass
+            FHE_DENSE_SYNC();          // the next polynomial's first stores vs the other wave's reads of this one's last pass
 #pragma unroll
             for (int col = 0; col < K1; col++)
 #pragma unroll
@@ -175,9 +183,9 @@ blind_rotate_dense_kernel(BlindRotateArgs args) {
                 own[own_slot(p, m, 0)] += from_torus(t.re);
                 own[own_slot(p, m, 1)] += from_torus(t.im);
             }
-            if (p + 1 < K1) __syncthreads();      // the next inverse's first stores land in the other wave's rows
+            if (p + 1 < K1) FHE_DENSE_SYNC();      // the next inverse's first stores land in the other wave's rows
         }
-        __syncthreads();
+        FHE_DENSE_SYNC();
     }
 
     // sample extraction (glwe_sample_extraction.rs:91-147)
