@@ -166,6 +166,14 @@ int fhe_engine_cluster_info(fhe_engine* eng, uint32_t* clusters) {
     API_END
 }
 
+int fhe_engine_cluster_fallbacks(fhe_engine* eng, uint32_t* count) {
+    API_BEGIN
+    CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(count);
+    *count = eng->impl->cluster_fallbacks;
+    return 0;
+    API_END
+}
+
 int fhe_lut_generate(fhe_engine* eng, const uint64_t* table, uint32_t* lut_id, uint64_t* degree) {
     API_BEGIN
     CHECK_PTR(eng); LOCK_ENGINE(eng); CHECK_PTR(table); CHECK_PTR(lut_id);

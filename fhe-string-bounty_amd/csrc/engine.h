@@ -54,6 +54,7 @@ struct EngineEnv {
     int multibit_combine_max = -1;    // FHESTR_MULTIBIT_COMBINE_MAX fhe_engine_set_multibit_combine_max at creation
     int cluster_test_fault = -1;      // FHESTR_CLUSTER_TEST_FAULT   honoured by the -DFHESTR_TEST_HOOKS build only
     int dense_per_cu = -1;            // FHESTR_DENSE_PER_CU         LWEs per CU beyond which the dense wide kernel runs (0 = never)
+    int cluster_fallback = -1;        // FHESTR_CLUSTER_FALLBACK     0: a multi-CU launch that gave up is an error, not re-run
     static EngineEnv read();
 };
 
@@ -124,6 +125,9 @@ struct Engine {
     void* d_cluster_ctl = nullptr;  // ClusterCtl (tickets, flags; zeroed per launch) + ClusterStatus (sticky)
     bool cluster_unchecked = false; // a cluster launch whose status words have not been read yet
     uint32_t cluster_last = 0;      // clusters the last checked launch formed
+    bool cluster_fallback = true;   // a multi-CU launch that gave up is re-run on the one-workgroup kernel (cluster_settle)
+    uint32_t cluster_fallbacks = 0; // how often that happened
+    uint32_t cluster_last_error = 0;
     int cluster_mode = -1;          // -1 automatic (by batch size), 0 never, 1 always (FHESTR_CLUSTER)
     uint32_t cluster_max_batch = 0xFFFFFFFFu;
     uint32_t ks_chunks_override = 0; // FHESTR_KS_CHUNKS: K chunks of the matrix-core keyswitch (0 = automatic)
@@ -146,6 +150,7 @@ struct Engine {
                       uint64_t* bsk_std_out, uint64_t* ksk_out);
     int install_keys(uint64_t* d_ksk_std, uint64_t* d_bsk_std);
     int convert_polys(const uint64_t* d_std, double* d_out, uint32_t n_polys);
+    int cluster_settle(const uint64_t* d_sm, const uint32_t* d_lut_idx, uint64_t* d_big, uint32_t count);
     int probe_slot_exponents();
     uint64_t fill_accumulator(const uint64_t* table, std::vector<uint64_t>& acc) const { return fhe::fill_accumulator(p, table, acc); }
     int lut_upload_dedup(const std::vector<uint64_t>& acc, uint32_t* id);   // same contents -> same id

@@ -303,6 +303,7 @@ EngineEnv EngineEnv::read() {
     num("FHESTR_LOG2_POINTS", v.log2_points);
     num("FHESTR_WIDE_FAIR", v.wide_fair);
     num("FHESTR_DENSE_PER_CU", v.dense_per_cu);
+    num("FHESTR_CLUSTER_FALLBACK", v.cluster_fallback);
     num("FHESTR_KEEP_BUSY", v.keep_busy);
     num("FHESTR_OVERLAP_STREAMS", v.overlap_streams);
     num("FHESTR_KS_MFMA", v.ks_mfma);
@@ -331,6 +332,7 @@ int Engine::create(const fhe_params_t& p, int device, Engine** out) {
     const EngineEnv env = EngineEnv::read();
     if (env.wide_fair >= 0) e->wide_fair_shift = (uint32_t)std::min(20, env.wide_fair);
     if (env.dense_per_cu >= 0) e->dense_per_cu = (uint32_t)env.dense_per_cu;
+    if (env.cluster_fallback >= 0) e->cluster_fallback = env.cluster_fallback != 0;
     if (env.keep_busy >= 0) e->keep_busy = env.keep_busy != 0;
     if (env.overlap_streams >= 0) e->ovl_streams = std::min((int)Engine::OVL_MAX, std::max(2, env.overlap_streams));
     if (env.ks_mfma >= 0) e->ks_mfma_enabled = env.ks_mfma != 0;
@@ -904,8 +906,7 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
                                   cluster_spin_limit, cluster_test_fault};
         void* kargs[] = {(void*)&ka};
         HIP_TRY(hipLaunchKernel(v->xcd_fn, dim3(grid), dim3(v->xcd_threads), kargs, lds, stream));
-        cluster_unchecked = true;
-        return 0;
+        return cluster_settle(d_sm, d_lut_idx, d_big, count);
     }
     if (v->cluster_fn && cluster_mode != 0 && (cluster_mode >= 1 || count <= cluster_max_batch) &&
         (uint32_t)cu_count >= 8u * (uint32_t)v->cluster_size) {
@@ -928,8 +929,7 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
                                   cluster_spin_limit, cluster_test_fault};
         void* kargs[] = {(void*)&ka};
         HIP_TRY(hipLaunchKernel(v->cluster_fn, dim3(grid), dim3(v->threads), kargs, v->cluster_lds + (size_t)p.n * 4, stream));
-        cluster_unchecked = true;
-        return 0;
+        return cluster_settle(d_sm, d_lut_idx, d_big, count);
     }
     if (v->large) {
         if (ensure(&d_ws, &cap_ws, (size_t)count * v->ws_bytes)) return 1;
@@ -1294,6 +1294,29 @@ void Engine::end_pipeline_run() {
 
 // The cluster kernel never hangs on a hand-over that does not arrive: it gives up, finishes with garbage and says so
 // in its status words.  Every host-visible completion point asks here.
+// A launch of one of the multi-CU kernels is settled before the call returns: the host waits for it, reads the
+// status words and, when the formation or a hand-over gave up -- a foreign kernel held compute units the grid needed;
+// the kernel drained with invalid results instead of hanging -- runs the same batch on the one-workgroup kernel, which
+// needs nothing resident but itself.  These kernels take 10 ms and more per launch: the synchronisation costs nothing
+// measurable.  FHESTR_CLUSTER_FALLBACK=0: the round-3 behaviour (checked at the next completion point, reported as an error).
+int Engine::cluster_settle(const uint64_t* d_sm, const uint32_t* d_lut_idx, uint64_t* d_big, uint32_t count) {
+    if (!cluster_fallback) { cluster_unchecked = true; return 0; }
+    ClusterStatus st{};
+    ClusterStatus* d_st = reinterpret_cast<ClusterStatus*>(reinterpret_cast<ClusterCtl*>(d_cluster_ctl) + 1);
+    HIP_TRY(hipMemcpyAsync(&st, d_st, sizeof(st), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    cluster_last = st.clusters;
+    if (!st.error) return 0;
+    HIP_TRY(hipMemsetAsync(d_st, 0, sizeof(st), stream));
+    cluster_fallbacks++;
+    cluster_last_error = st.error;
+    const int saved = cluster_mode;
+    cluster_mode = 0;
+    const int rc = launch_blind_rotate(d_sm, d_lut_idx, d_big, count);
+    cluster_mode = saved;
+    return rc;
+}
+
 int Engine::cluster_check() {
     if (!cluster_unchecked || !d_cluster_ctl) return 0;
     ClusterStatus st{};

@@ -125,7 +125,7 @@ _lib = None
 EXPORTS = [
     "fhe_last_error", "fhe_kernel_revision", "fhe_engine_create", "fhe_engine_destroy", "fhe_engine_params",
     "fhe_engine_load_keys", "fhe_engine_generate_keys", "fhe_engine_stream", "fhe_engine_synchronize", "fhe_engine_set_variant",
-    "fhe_engine_set_multibit_combine_max", "fhe_engine_set_cluster_mode", "fhe_engine_set_keep_busy", "fhe_engine_pipeline_input_event", "fhe_engine_cluster_info", "fhe_engine_load_seeded_keys", "fhe_engine_set_pipeline",
+    "fhe_engine_set_multibit_combine_max", "fhe_engine_set_cluster_mode", "fhe_engine_set_keep_busy", "fhe_engine_pipeline_input_event", "fhe_engine_cluster_info", "fhe_engine_cluster_fallbacks", "fhe_engine_load_seeded_keys", "fhe_engine_set_pipeline",
     "fhe_lut_generate", "fhe_lut_upload", "fhe_lut_download", "fhe_lut_count",
     "fhe_keyswitch_batch", "fhe_pbs_batch", "fhe_ks_pbs_batch", "fhe_ks_pbs_batch_dev", "fhe_pbs_ks_batch",
     "fhe_lwe_lincomb_batch", "fhe_last_kernel_ms", "fhe_kernel_times",
@@ -204,6 +204,7 @@ def lib() -> C.CDLL:
     sig("fhe_engine_set_cluster_mode", vp, i32, u32)
     sig("fhe_engine_set_keep_busy", vp, C.c_int)
     sig("fhe_engine_cluster_info", vp, C.POINTER(u32))
+    sig("fhe_engine_cluster_fallbacks", vp, C.POINTER(u32))
     sig("fhe_engine_load_seeded_keys", vp, vp, vp, vp, vp, vp, vp)
     sig("fhe_engine_expand_seeded_lwe", vp, vp, vp, u32, vp, vp)
     sig("fhe_lut_generate", vp, vp, C.POINTER(u32), C.POINTER(C.c_uint64))
@@ -428,6 +429,12 @@ class Engine:
         """Clusters the last cluster launch formed (synchronises)."""
         n = C.c_uint32(0)
         _check(lib().fhe_engine_cluster_info(self._h, C.byref(n)))
+        return n.value
+
+    def cluster_fallbacks(self) -> int:
+        """How often a multi-CU launch gave up (compute units held by another kernel) and was re-run on the one-workgroup kernel."""
+        n = C.c_uint32(0)
+        _check(lib().fhe_engine_cluster_fallbacks(self._h, C.byref(n)))
         return n.value
 
     def set_multibit_combine_max(self, max_batch: int):

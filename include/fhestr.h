@@ -130,6 +130,10 @@ int fhe_engine_set_cluster_mode(fhe_engine *eng, int mode, uint32_t max_batch);
 int fhe_engine_set_keep_busy(fhe_engine *eng, int on);
 /* After a synchronisation: clusters the last cluster launch formed (0 if none ran). */
 int fhe_engine_cluster_info(fhe_engine *eng, uint32_t *clusters);
+/* The multi-CU kernels need their whole grid resident at once; when another kernel holds compute units for too long
+ * the launch drains with a status instead of hanging, and the engine runs the same batch again on the one-workgroup
+ * kernel before the call returns (correct results, that launch's time lost).  count = how often this engine did so. */
+int fhe_engine_cluster_fallbacks(fhe_engine *eng, uint32_t *count);
 
 /* ---- lookup tables ------------------------------------------------------------------------- */
 /* generate_lookup_table (shortint/server_key/mod.rs:383-399, engine/mod.rs:72-128):

@@ -104,10 +104,12 @@ TESTHOOKS_LIB = _os.path.join(ROOT_DIR, "build", "testhooks", "libfhestr_testhoo
 
 
 @pytest.mark.parametrize("mode", [1, 2])
-def test_a_missing_hand_over_is_reported_not_hung(mode):
+def test_a_missing_hand_over_is_recovered_or_reported_never_hung(mode):
     """Fault injection: one workgroup of one cluster never publishes one of its epoch flags.  The waits of that cluster
-    give up after the (lowered) poll limit, the launch drains, the next host-visible completion point returns an error
-    -- and the engine is usable again afterwards.  A hand-over that never comes must never hang the GPU.
+    give up after the (lowered) poll limit and the launch drains.  Default: the engine notices before the call returns
+    and runs the batch again on the one-workgroup kernel -- correct results, `cluster_fallbacks` counts it.  With
+    FHESTR_CLUSTER_FALLBACK=0 (round 3's behaviour) the next host-visible completion point returns an error and the engine
+    is usable again afterwards.  A hand-over that never comes must never hang the GPU nor hand out a wrong ciphertext.
     The hook (FHESTR_CLUSTER_TEST_FAULT) exists only in the -DFHESTR_TEST_HOOKS build of the library
     (`make -C fhe-string-bounty_amd testhooks`, built by __graft_entry__.build()); the product library ignores it."""
     import os
@@ -128,23 +130,26 @@ lut, _ = eng.generate_lookup_table(lambda x: (x + 1) % M)
 cts = ck.encrypt_many([1, 2, 3], O.Rng(1, 1))
 eng.set_cluster_mode(int(sys.argv[1]))
 try:
-    eng.apply_lookup_table(cts, np.full(3, lut, dtype=np.uint32))
-    print("NO ERROR")
+    out = eng.apply_lookup_table(cts, np.full(3, lut, dtype=np.uint32))
+    print("NO ERROR", "decrypts", [int(ck.decrypt(c)) for c in out], "fallbacks", eng.cluster_fallbacks())
 except fhestr.FheError as e:
     print("ERROR:", e)
 '''
     base = {k: v for k, v in os.environ.items() if k not in ("FHESTR_LIB", "FHESTR_CLUSTER_TEST_FAULT")}
     hooks = dict(base, FHESTR_LIB=TESTHOOKS_LIB, FHESTR_CLUSTER_TEST_FAULT="5", FHESTR_CLUSTER_SPIN_LIMIT="4096")
     r = subprocess.run([sys.executable, "-c", code, str(mode)], env=hooks, cwd=ROOT_DIR, capture_output=True, text=True, timeout=300)
+    assert "NO ERROR decrypts [2, 3, 4] fallbacks 1" in r.stdout, r.stdout + r.stderr[-1000:]
+    r = subprocess.run([sys.executable, "-c", code, str(mode)], env=dict(hooks, FHESTR_CLUSTER_FALLBACK="0"), cwd=ROOT_DIR,
+                       capture_output=True, text=True, timeout=300)
     assert "ERROR:" in r.stdout and "hand-over timed out" in r.stdout, r.stdout + r.stderr[-1000:]
-    # the product library has no such hook: the same environment runs clean
+    # the product library has no such hook: the same environment runs clean, nothing to recover from
     prod = dict(base, FHESTR_CLUSTER_TEST_FAULT="5", FHESTR_CLUSTER_SPIN_LIMIT="4096")
     r = subprocess.run([sys.executable, "-c", code, str(mode)], env=prod, cwd=ROOT_DIR, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "NO ERROR" in r.stdout, r.stdout + r.stderr[-1000:]
+    assert r.returncode == 0 and "NO ERROR decrypts [2, 3, 4] fallbacks 0" in r.stdout, r.stdout + r.stderr[-1000:]
     # and the test build without the fault works too
     hooks.pop("FHESTR_CLUSTER_TEST_FAULT")
     r = subprocess.run([sys.executable, "-c", code, str(mode)], env=hooks, cwd=ROOT_DIR, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "NO ERROR" in r.stdout, r.stdout + r.stderr[-1000:]
+    assert r.returncode == 0 and "NO ERROR decrypts [2, 3, 4] fallbacks 0" in r.stdout, r.stdout + r.stderr[-1000:]
 
 
 @pytest.mark.parametrize("shape,mode", [(O.TOY_N32768, 1), (O.TOY_N32768, 2), ([p for p in O.TOY_SHAPES if p.N == 16384][0], 1)],
@@ -153,8 +158,9 @@ def test_cluster_launch_while_another_engine_holds_the_compute_units(p22, shape,
     """the multi-CU kernels need their whole grid resident at once.  Here a second engine keeps every CU
     busy with long blind_rotate_wide_kernel batches (2,048 LWEs of PARAM_MESSAGE_2_CARRY_2, about 16 ms each, two workgroups per
     CU) while cluster batches are launched from another stream at varying offsets into them.  Every cluster result must be
-    correct -- its workgroups queue until CUs free up, the formation wait is bounded but long enough -- or the call must raise
-    the documented 'hand-over timed out' error; a wrong ciphertext without an error is the one outcome that may not happen.
+    correct -- its workgroups queue until CUs free up, the formation wait is bounded but long enough, and a launch that gave
+    up all the same is run again on the one-workgroup kernel before the call returns (cluster_settle; counted) -- a wrong
+    ciphertext without an error is the one outcome that may not happen, and since round 4 an error is none either.
     The other engine's results are checked too."""
     import time
     import fhestr
@@ -176,6 +182,7 @@ def test_cluster_launch_while_another_engine_holds_the_compute_units(p22, shape,
     torch.cuda.synchronize()
     eng_b.set_cluster_mode(mode)
     timeouts = 0
+    fallbacks_before = eng_b.cluster_fallbacks()
     try:
         for trial in range(8):
             count = (3, 8, 17, 40)[trial % 4]
@@ -194,7 +201,9 @@ def test_cluster_launch_while_another_engine_holds_the_compute_units(p22, shape,
             assert np.array_equal(p22.ck.decrypt_many(d_out.cpu().numpy().view(np.uint64)[:64]), (msgs_a[:64] + 3) % Ma)
     finally:
         eng_b.set_cluster_mode(-1)
-    print(f"{shape.name} mode {mode}: {timeouts} of 8 launches reported a hand-over time-out, the rest were correct")
+    print(f"{shape.name} mode {mode}: {timeouts} of 8 launches reported a hand-over time-out, "
+          f"{eng_b.cluster_fallbacks() - fallbacks_before} were re-run on the one-workgroup kernel, all results handed out were correct")
+    assert timeouts == 0       # since round 4 a launch that gave up is re-run before the call returns (cluster_settle)
     # after the contention: a clean launch works
     enc_b = ks_b.ck.encrypt_many([1, 2, 3], O.Rng(73, 1))
     got = eng_b.apply_lookup_table(enc_b, np.full(3, lut_b, dtype=np.uint32))
