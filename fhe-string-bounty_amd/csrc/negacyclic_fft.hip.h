@@ -666,13 +666,9 @@ __device__ __forceinline__ void swap10_inverse(cplx (*x)[4], const FftConsts<Fft
 #endif
 // FftSwap9: passes 1-4 and both in-wave exchanges are FftSwap10's stages (slab rows 4w + r, two waves); the pass across the
 // waves is a radix-2.
-__device__ __forceinline__ void swap9_forward(cplx* x, const FftConsts<FftSwap9>& c, double* re, double* im, int tau) {
-    swap10_fwd_stage1(x, c, re, im, tau);
-    wave_local_fence();
-    swap10_fwd_stage2(x, c, re, im, tau);
-    wave_local_fence();          // the slab stores below reuse the rows the exchange above read
-    swap10_fwd_stage3(x, c, re, im, tau);
-    FHE_DENSE_SYNC();
+// The pieces, for callers that put independent work of their own between them (the dense kernel: the previous polynomial's
+// products behind stage 1's LDS stores, its accumulator update behind the inverse's first stores).
+__device__ __forceinline__ void swap9_forward_tail(cplx* x, const double* re, const double* im, int tau) {
     const int lane = tau & 63, w = tau >> 6;
 #pragma unroll
     for (int rl = 0; rl < 2; rl++) {
@@ -682,7 +678,7 @@ __device__ __forceinline__ void swap9_forward(cplx* x, const FftConsts<FftSwap9>
         x[2 * rl + 1].re = ar - br; x[2 * rl + 1].im = ai - bi;
     }
 }
-__device__ __forceinline__ void swap9_inverse(cplx* x, const FftConsts<FftSwap9>& c, double* re, double* im, int tau) {
+__device__ __forceinline__ void swap9_inverse_head(const cplx* x, double* re, double* im, int tau) {
     const int lane = tau & 63, w = tau >> 6;
 #pragma unroll
     for (int rl = 0; rl < 2; rl++) {
@@ -692,12 +688,28 @@ __device__ __forceinline__ void swap9_inverse(cplx* x, const FftConsts<FftSwap9>
         re[a1] = x[2 * rl].re - x[2 * rl + 1].re; im[a1] = x[2 * rl].im - x[2 * rl + 1].im;
         FHE_PIN_ORDER();
     }
-    FHE_DENSE_SYNC();
+}
+template <class C>
+__device__ __forceinline__ void swap9_inverse_tail(cplx* x, const C& c, double* re, double* im, int tau) {
     swap10_inv_stage1(x, c, re, im, tau);
     wave_local_fence();          // the exchange below reuses the slab rows just read
     swap10_inv_stage2(x, c, re, im, tau);
     wave_local_fence();
     swap10_inv_stage3(x, c, re, im, tau);
+}
+__device__ __forceinline__ void swap9_forward(cplx* x, const FftConsts<FftSwap9>& c, double* re, double* im, int tau) {
+    swap10_fwd_stage1(x, c, re, im, tau);
+    wave_local_fence();
+    swap10_fwd_stage2(x, c, re, im, tau);
+    wave_local_fence();          // the slab stores below reuse the rows the exchange above read
+    swap10_fwd_stage3(x, c, re, im, tau);
+    FHE_DENSE_SYNC();
+    swap9_forward_tail(x, re, im, tau);
+}
+__device__ __forceinline__ void swap9_inverse(cplx* x, const FftConsts<FftSwap9>& c, double* re, double* im, int tau) {
+    swap9_inverse_head(x, re, im, tau);
+    FHE_DENSE_SYNC();
+    swap9_inverse_tail(x, c, re, im, tau);
 }
 
 // Forward transform.  In: x[m] = point (tau + T*m) of the (already twisted) input.

@@ -12,19 +12,16 @@
 //     traffic per step, 48 VGPRs saved), at most 256 VGPRs: 36 KB per workgroup, two waves on every SIMD;
 //   * transforms on FftSwap9 (negacyclic_fft.hip.h): two of the four inter-pass exchanges are register/lane swaps and the
 //     twiddles sit in registers.  The first dense version ran the generic plan (every exchange and a twiddle table through
-//     LDS, 550 KB per workgroup-step): 133-138 k PBS/s; this one 137-146 k.  VALU issue is ~50 % of the time: what is left is
+//     LDS, 550 KB per workgroup-step): 133-138 k PBS/s; this one 137-146 k, 142-151 k with the inverse twiddles folded,
+//     145-162 k with the two sides pipelined by hand (same box: +2 %).  VALU issue is ~55 % of the time: what is left is
 //     the dependent chain of one polynomial's transform at a time (the wide kernel interleaves its polynomials stage by
-//     stage, which needs a plane set each) and 12 two-wave barriers per step.
+//     stage, which needs a plane set each); ablation builds show that neither the barriers, the gather nor the key loads
+//     are it (profiles/r04_n1024.txt).
 // The Fourier key is read in FftSwap9's order: a second copy of the key (54.7 MB) made by bsk_convert_dense_kernel.
 #pragma once
 #include "pbs_kernels.hip.h"
 
 namespace fhe {
-
-#ifndef FHESTR_DENSE_ROW_PREFETCH
-#define FHESTR_DENSE_ROW_PREFETCH 0      // 1: request a GGSW row before the transform in front of it instead of after (measured: 139 against
-                                         // 144 k PBS/s at 2,048 LWEs -- eight waves per CU hide the L2 latency, the registers are better left free)
-#endif
 
 template <int LOGN, int K1>
 struct BrDenseCfg {
@@ -104,7 +101,6 @@ blind_rotate_dense_kernel(BlindRotateArgs args) {
     constexpr size_t GGSW_ELEMS = (size_t)K1 * K1 * P;
     const uint32_t key_off = (uint32_t)tau * 16u;
     const auto key_rsrc = key_resource(args.fbsk, (size_t)n * GGSW_ELEMS * 16);
-    constexpr bool ROW_PREFETCH = FHESTR_DENSE_ROW_PREFETCH;
 
     uint32_t d_next = lds_d[0];
     for (uint32_t i = 0; i < n; i++) {
@@ -125,9 +121,31 @@ blind_rotate_dense_kernel(BlindRotateArgs args) {
                     brow[col][rho] = key_load(key_rsrc, key_off, (uint32_t)((i * GGSW_ELEMS + ((size_t)row * K1 + col) * P + rho * T) * 16));
 #endif
         };
-        if (ROW_PREFETCH) request_row(0);
-
         cplx outf[K1][R];
+        // products of one polynomial's spectrum with its GGSW row (ggsw.rs:560-598)
+        auto multiply_row = [&](int row, const cplx* f4) {
+#pragma unroll
+            for (int col = 0; col < K1; col++)
+#pragma unroll
+                for (int rho = 0; rho < R; rho++) {
+                    const double2 bv = brow[col][rho];
+                    const cplx f = f4[rho];
+                    if (row == 0) {
+                        outf[col][rho].re = bv.x * f.re - bv.y * f.im;
+                        outf[col][rho].im = bv.x * f.im + bv.y * f.re;
+                    } else {
+                        outf[col][rho].re = fma(bv.x, f.re, fma(-bv.y, f.im, outf[col][rho].re));
+                        outf[col][rho].im = fma(bv.x, f.im, fma(bv.y, f.re, outf[col][rho].im));
+                    }
+                }
+        };
+        double* const xre = lds_x;
+        double* const xim = lds_x + CFG::PLANE;
+
+        // Forward side, software-pipelined by hand (each wave runs ONE dependent chain at a time here, so whatever is
+        // independent is placed where the chain waits): polynomial `row`'s products are issued behind the LDS stores of
+        // polynomial row + 1's first stage; its GGSW row is requested before the barrier of its own transform.
+        cplx spec[R];               // the previous polynomial's spectrum
 #pragma unroll
         for (int row = 0; row < K1; row++) {
             // ct1 = acc * X^d - acc of polynomial `row` (polynomial_algorithms.rs:463-489), decomposed, twisted
@@ -152,39 +170,40 @@ blind_rotate_dense_kernel(BlindRotateArgs args) {
                 }
                 xr[m] = digit_point(st[0], st[1], twist[m], twbias[m]);      // fft/mod.rs:220-239
             }
-            fft_forward<PL>(xr, fc, lds_x, lds_x + CFG::PLANE, tau);
-            if (!ROW_PREFETCH) request_row(row);
-            FHE_DENSE_SYNC();          // the next polynomial's first stores vs the other wave's reads of this one's last pass
+            swap10_fwd_stage1(xr, fc, xre, xim, tau);
+            if (row > 0) multiply_row(row - 1, spec);
+            wave_local_fence();
+            swap10_fwd_stage2(xr, fc, xre, xim, tau);
+            wave_local_fence();          // the slab stores below reuse the rows the exchange above read
+            swap10_fwd_stage3(xr, fc, xre, xim, tau);
+            request_row(row);
+            FHE_DENSE_SYNC();
+            swap9_forward_tail(xr, xre, xim, tau);
+            FHE_DENSE_SYNC();            // the next polynomial's first stores vs the other wave's reads of this one's last pass
 #pragma unroll
-            for (int col = 0; col < K1; col++)
-#pragma unroll
-                for (int rho = 0; rho < R; rho++) {
-                    const double2 bv = brow[col][rho];
-                    const cplx f = xr[rho];
-                    if (row == 0) {
-                        outf[col][rho].re = bv.x * f.re - bv.y * f.im;
-                        outf[col][rho].im = bv.x * f.im + bv.y * f.re;
-                    } else {
-                        outf[col][rho].re = fma(bv.x, f.re, fma(-bv.y, f.im, outf[col][rho].re));
-                        outf[col][rho].im = fma(bv.x, f.im, fma(bv.y, f.re, outf[col][rho].im));
-                    }
-                }
-            FHE_PIN_ORDER();
-            if (ROW_PREFETCH && row + 1 < K1) request_row(row + 1);
+            for (int rho = 0; rho < R; rho++) spec[rho] = xr[rho];
         }
+        multiply_row(K1 - 1, spec);
 
-        // every gather of this step is done (the barrier after the last forward transform): the accumulator may change
-#pragma unroll
-        for (int p = 0; p < K1; p++) {
-            fft_inverse<PL>(outf[p], fc, lds_x, lds_x + CFG::PLANE, tau);
+        // every gather of this step is done (the barrier after the last forward transform): the accumulator may change.
+        // Inverse side: polynomial p - 1's accumulator update goes behind polynomial p's first stores.
+        auto update_acc = [&](int p) {
 #pragma unroll
             for (int m = 0; m < R; m++) {
                 const cplx t = cmul_conj(outf[p][m], twist[m]);
                 own[own_slot(p, m, 0)] += from_torus(t.re);
                 own[own_slot(p, m, 1)] += from_torus(t.im);
             }
+        };
+#pragma unroll
+        for (int p = 0; p < K1; p++) {
+            swap9_inverse_head(outf[p], xre, xim, tau);
+            if (p > 0) update_acc(p - 1);
+            FHE_DENSE_SYNC();
+            swap9_inverse_tail(outf[p], fc, xre, xim, tau);
             if (p + 1 < K1) FHE_DENSE_SYNC();      // the next inverse's first stores land in the other wave's rows
         }
+        update_acc(K1 - 1);
         FHE_DENSE_SYNC();
     }
 
