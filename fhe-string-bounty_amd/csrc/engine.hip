@@ -58,6 +58,7 @@ struct BrVariant {
     size_t convert_lds;
     const void* rotate_fn;
     const void* convert_fn;
+    bool convert_one_per_block = false;   // the conversion kernel takes one polynomial per workgroup (K1 otherwise)
     // multi-bit, small batches: build every (LWE, group) GGSW on the whole GPU first, then rotate against them
     const void* combine_fn = nullptr;
     const void* rotate_combined_fn = nullptr;
@@ -107,6 +108,12 @@ BrVariant make_wide_variant() {
     v.threads = CFG::THREADS;
     v.lds_bytes = CFG::LDS_FIXED;
     v.rotate_fn = reinterpret_cast<const void*>(&blind_rotate_wide_kernel<LOGN, LOGR, K1, L>);
+    if constexpr (CFG::OWN_PLAN) {        // N = 4096: FftSwap11 -- the key in that plan's order, one polynomial per workgroup
+        v.convert_fn = reinterpret_cast<const void*>(&bsk_convert_wide_kernel<LOGN, LOGR, K1, L>);
+        v.convert_threads = CFG::THREADS;
+        v.convert_lds = (size_t)CFG::GROUP_SLOTS * 8;
+        v.convert_one_per_block = true;
+    }
     if constexpr (LOGN == 10 && LOGR == 2 && K1 == 3 && L == 1) {       // N = 1024, k = 2 (pbs_dense_kernels.hip.h)
         using DC = BrDenseCfg<LOGN, K1>;
         static_assert(DC::THREADS == CFG::THREADS, "same launch shape as the wide kernel");
@@ -574,8 +581,8 @@ int Engine::convert_polys(const uint64_t* d_std, double* d_out, uint32_t n_polys
         return 0;
     }
     void* args[] = {(void*)&d_std, (void*)&d_out, (void*)&n_polys};
-    HIP_TRY(hipLaunchKernel(variant->convert_fn, dim3((n_polys + k1 - 1) / k1), dim3(variant->convert_threads),
-                            args, variant->convert_lds, stream));
+    HIP_TRY(hipLaunchKernel(variant->convert_fn, dim3(variant->convert_one_per_block ? n_polys : (n_polys + k1 - 1) / k1),
+                            dim3(variant->convert_threads), args, variant->convert_lds, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return 0;
 }

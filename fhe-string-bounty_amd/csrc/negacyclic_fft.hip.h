@@ -217,6 +217,36 @@ struct FftSwap9 {
     __host__ __device__ static constexpr int acc_slot(int j) { return ((j & 1) << 9) | (j >> 1); }
 };
 
+// P = 2048 points, 4 per thread, 512 threads (8 waves): N = 4096 (round 4).  The generic plan moves every point through LDS
+// five times per transform -- 655 KB of LDS stores per CMUX step against ~85 B/clk/CU for ds_write_b64: the LDS pipe was
+// busy half of the time, VALU a third.  Here j = 512 m + 8 lane + wave; radix-4 passes on (b10b9)(b8b7)(b6b5)(b4b3) with
+// FftSwap10's two register/lane swaps and wave-local exchange, then ONE radix-8 pass on (b2b1b0) across the eight waves:
+//   all four registers to the wave's slab rows 4w + r (32 rows of 64 slots; workgroup barrier), then the thread of wave w
+//   takes r = w >> 1 and the output parity h = w & 1: it reads the 8 inputs of (r, lane), forms u[n'] = x[n'] + x[n'+4]
+//   (h = 0) or (x[n'] - x[n'+4]) w8^n' (h = 1) and runs one radix-4 on them: outputs X[2q + h] in register q.
+// The inverse mirrors it: radix-4 on the thread's four X[2q + h], times conj(w8^n') for h = 1, into rows 16 h + 4 n' + r;
+// after the barrier wave n adds (b2 = 0) or subtracts (b2 = 1) the even and odd halves of its own four points while loading.
+// Two waves share every row they read across the barrier, so -- unlike FftSwap10's slab/comb -- a barrier separates the
+// forward transform's last loads from the inverse's first stores, and the inverse's first loads from its next stores.
+struct FftSwap11 {
+    static constexpr bool SWAP = true;
+    static constexpr int LOGW = 3;
+    static constexpr int LOGP = 11;
+    static constexpr int LOGR = 2;
+    static constexpr int P = 2048;
+    static constexpr int R = 4;
+    static constexpr int T = 512;
+    static constexpr int FULL = 4;
+    static constexpr int LOGLAST = 3;
+    static constexpr int NP = 5;
+    static constexpr int NTW = 4;
+    __host__ __device__ static constexpr int log_radix(int s) { return s < 4 ? 2 : 3; }
+    __host__ __device__ static constexpr int log_S(int s) { return 11 - 2 * s; }
+    __host__ __device__ static constexpr int point(int tau, int m) { return 512 * m + 8 * (tau & 63) + (tau >> 6); }
+    // accumulator copy (N = 4096 coefficients): slot = (j mod 8) * 512 + j / 8
+    __host__ __device__ static constexpr int acc_slot(int j) { return ((j & 7) << 9) | (j >> 3); }
+};
+
 // Plan used by the blind-rotation kernels for (log2 P, log2 R).
 template <int LP, int LR>
 struct PlanFor { using type = FftPlan<LP, LR>; };
@@ -394,7 +424,7 @@ __device__ __forceinline__ void fft_init_consts(FftConsts<PL>& c, int tau) {
             int w = tau >> 6;
             // FftSwap9, last twiddled pass: the angle depends on the wave number alone -- scalar registers (the dense
             // kernel has none of the vector kind to spare)
-            if constexpr (PL::LOGP == 9) { if (s == 3) w = __builtin_amdgcn_readfirstlane(w); }
+            if constexpr (PL::LOGP == 9 || PL::LOGP == 11) { if (s == 3) w = __builtin_amdgcn_readfirstlane(w); }
             constexpr int LW = PL::SWAP ? (PL::LOGP - 8) : 0;       // FftSwap10: 2 wave bits, FftSwap9: 1
             tp = s == 0 ? ((lane << LW) | w) : s == 1 ? (((lane & 15) << LW) | w) : s == 2 ? (((lane >> 4) << LW) | w) : w;
         }
@@ -579,9 +609,15 @@ __device__ __forceinline__ void swap10_inverse_head(const cplx* x, double* re, d
     });
 }
 template <class C>
+__device__ __forceinline__ void swap10_inv_stage1_compute(cplx* x, const C& c);
+template <class C>
 __device__ __forceinline__ void swap10_inv_stage1(cplx* x, const C& c, const double* re, const double* im, int tau) {
 #pragma unroll
     for (int r = 0; r < 4; r++) { const int a = swap10_slab(tau, r); x[r].re = re[a]; x[r].im = im[a]; }
+    swap10_inv_stage1_compute(x, c);
+}
+template <class C>
+__device__ __forceinline__ void swap10_inv_stage1_compute(cplx* x, const C& c) {
     if (FHESTR_FUSED_IDFT) {
         idft4_twiddled(x, c.tw[3]);
         swap_regs_lanes(x);           // the twiddles of the next pass (c.tw[2]) are folded into stage 2's butterfly
@@ -712,6 +748,97 @@ __device__ __forceinline__ void swap9_inverse(cplx* x, const FftConsts<FftSwap9>
     swap9_inverse_tail(x, c, re, im, tau);
 }
 
+// ---- FftSwap11 (2048 points, eight waves) ------------------------------------------------------------------------
+__device__ __forceinline__ void swap11_forward_tail(cplx* x, const double* re, const double* im, int tau) {
+    const int lane = tau & 63, w = __builtin_amdgcn_readfirstlane(tau >> 6), r = w >> 1;
+    cplx in[8];
+#pragma unroll
+    for (int n = 0; n < 8; n++) { const int a = ((4 * n + r) << 6) | lane; in[n].re = re[a]; in[n].im = im[a]; }
+    constexpr double C8 = 0.70710678118654752440;
+    if ((w & 1) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { x[q].re = in[q].re + in[q + 4].re; x[q].im = in[q].im + in[q + 4].im; }
+    } else {                                       // (x[n'] - x[n'+4]) * exp(-2 pi i n' / 8)
+        cplx d[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { d[q].re = in[q].re - in[q + 4].re; d[q].im = in[q].im - in[q + 4].im; }
+        x[0] = d[0];
+        x[1].re = (d[1].re + d[1].im) * C8; x[1].im = (d[1].im - d[1].re) * C8;
+        x[2].re = d[2].im;                  x[2].im = -d[2].re;
+        x[3].re = (d[3].im - d[3].re) * C8; x[3].im = -(d[3].re + d[3].im) * C8;
+    }
+    small_dft<4, false>(x);
+}
+__device__ __forceinline__ void swap11_inverse_head(const cplx* x, double* re, double* im, int tau) {
+    const int lane = tau & 63, w = __builtin_amdgcn_readfirstlane(tau >> 6), r = w >> 1, h = w & 1;
+    cplx v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[q] = x[q];
+    small_dft<4, true>(v);
+    constexpr double C8 = 0.70710678118654752440;
+    if (h) {                                       // * exp(+2 pi i n' / 8)
+        cplx t;
+        t.re = (v[1].re - v[1].im) * C8; t.im = (v[1].re + v[1].im) * C8; v[1] = t;
+        t.re = -v[2].im;                 t.im = v[2].re;                  v[2] = t;
+        t.re = -(v[3].re + v[3].im) * C8; t.im = (v[3].re - v[3].im) * C8; v[3] = t;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int a = ((16 * h + 4 * q + r) << 6) | lane;
+        re[a] = v[q].re; im[a] = v[q].im;
+        FHE_PIN_ORDER();
+    }
+}
+// wave n = 4 b2 + n': its points r = 0..3 are E[n'][r] +- O[n'][r]
+__device__ __forceinline__ void swap11_inverse_gather(cplx* x, const double* re, const double* im, int tau) {
+    const int lane = tau & 63, w = __builtin_amdgcn_readfirstlane(tau >> 6), np = w & 3;
+    const double sg = (w >> 2) ? -1.0 : 1.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int a = ((4 * np + r) << 6) | lane, b = ((16 + 4 * np + r) << 6) | lane;
+        x[r].re = fma(sg, re[b], re[a]);
+        x[r].im = fma(sg, im[b], im[a]);
+    }
+}
+template <int NPOLY>
+__device__ __forceinline__ void swap11_forward(cplx (*x)[4], const FftConsts<FftSwap11>& c, double* re0, int poly_stride, int im_off, int tau) {
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap10_fwd_stage1(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    wave_local_fence();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap10_fwd_stage2(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    wave_local_fence();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap10_fwd_stage3(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) {
+        swap11_forward_tail(x[p], re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+        FHE_PIN_ORDER();         // one polynomial's eight inputs in registers at a time
+    }
+    __syncthreads();             // rows are shared by pairs of waves: nobody stores into them before everybody has read
+}
+template <int NPOLY>
+__device__ __forceinline__ void swap11_inverse(cplx (*x)[4], const FftConsts<FftSwap11>& c, double* re0, int poly_stride, int im_off, int tau) {
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) {
+        swap11_inverse_head(x[p], re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+        FHE_PIN_ORDER();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap11_inverse_gather(x[p], re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    __syncthreads();             // the wave-local exchange below stores into rows other waves have just read
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap10_inv_stage1_compute(x[p], c);
+    wave_local_fence();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap10_inv_stage2(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    wave_local_fence();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap10_inv_stage3(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+}
+
 // Forward transform.  In: x[m] = point (tau + T*m) of the (already twisted) input.
 // Out: x[rho] in last-pass layout.  `re`/`im` are this group's LDS planes (P doubles each).
 template <class PL, class C>
@@ -719,6 +846,9 @@ __device__ __forceinline__ void fft_forward(cplx* x, const C& c, double* re, dou
                                             int tau) {
     if constexpr (PL::SWAP && PL::LOGP == 9) {
         swap9_forward(x, c, re, im, tau);
+        return;
+    } else if constexpr (PL::SWAP && PL::LOGP == 11) {
+        swap11_forward<1>(reinterpret_cast<cplx(*)[4]>(x), c, re, 0, (int)(im - re), tau);
         return;
     } else if constexpr (PL::SWAP) {
         swap10_forward<1>(reinterpret_cast<cplx(*)[4]>(x), c, re, 0, (int)(im - re), tau);
@@ -774,6 +904,9 @@ __device__ __forceinline__ void fft_inverse(cplx* x, const C& c, double* re, dou
                                             int tau) {
     if constexpr (PL::SWAP && PL::LOGP == 9) {
         swap9_inverse(x, c, re, im, tau);
+        return;
+    } else if constexpr (PL::SWAP && PL::LOGP == 11) {
+        swap11_inverse<1>(reinterpret_cast<cplx(*)[4]>(x), c, re, 0, (int)(im - re), tau);
         return;
     } else if constexpr (PL::SWAP) {
         swap10_inverse<1>(reinterpret_cast<cplx(*)[4]>(x), c, re, 0, (int)(im - re), tau);
@@ -903,8 +1036,11 @@ __device__ __forceinline__ bool pass_sync_is_wave_local(int log_S_next) { return
 template <class PL, int NPOLY, class C>
 __device__ __forceinline__ void fft_forward_multi(cplx (*x)[PL::R], const C& c, double* re0,
                                                   int poly_stride, int im_off, int tau) {
-    static_assert(!PL::SWAP || PL::LOGP == 10, "several polynomials per thread: FftSwap10 only");
-    if constexpr (PL::SWAP) {
+    static_assert(!PL::SWAP || PL::LOGP == 10 || PL::LOGP == 11, "several polynomials per thread: FftSwap10 / FftSwap11");
+    if constexpr (PL::SWAP && PL::LOGP == 11) {
+        swap11_forward<NPOLY>(x, c, re0, poly_stride, im_off, tau);
+        return;
+    } else if constexpr (PL::SWAP) {
         swap10_forward<NPOLY>(x, c, re0, poly_stride, im_off, tau);
         return;
     }
@@ -936,8 +1072,11 @@ __device__ __forceinline__ void fft_forward_multi(cplx (*x)[PL::R], const C& c, 
 template <class PL, int NPOLY, class C>
 __device__ __forceinline__ void fft_inverse_multi(cplx (*x)[PL::R], const C& c, double* re0,
                                                   int poly_stride, int im_off, int tau) {
-    static_assert(!PL::SWAP || PL::LOGP == 10, "several polynomials per thread: FftSwap10 only");
-    if constexpr (PL::SWAP) {
+    static_assert(!PL::SWAP || PL::LOGP == 10 || PL::LOGP == 11, "several polynomials per thread: FftSwap10 / FftSwap11");
+    if constexpr (PL::SWAP && PL::LOGP == 11) {
+        swap11_inverse<NPOLY>(x, c, re0, poly_stride, im_off, tau);
+        return;
+    } else if constexpr (PL::SWAP) {
         swap10_inverse<NPOLY>(x, c, re0, poly_stride, im_off, tau);
         return;
     }

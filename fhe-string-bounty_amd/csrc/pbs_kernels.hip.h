@@ -618,11 +618,21 @@ blind_rotate_kernel(BlindRotateArgs args) {
 // k+1 independent FFT streams to overlap LDS round trips with butterflies, and the smaller
 // footprint (accumulator copy + exchange planes) lets two LWEs share a CU for batches >= 512.
 // Barriers per CMUX step: forward exchange 0->1, inverse exchange 1->0, accumulator publish.
+// FftSwap11 for N = 4096 (negacyclic_fft.hip.h): correct (decrypt and oracle-phase tests of the five N = 4096 sets pass with it)
+// and 60 % fewer LDS stores, but as compiled today its twiddles push the wide kernel to 51 / 69 spilled registers whose
+// reloads queue behind the prefetched key rows: 11.9 ms per 256 LWEs against 7.55 on the generic plan (profiles/r04_n4096.txt).
+// Off until the register budget is sorted out (twiddles of passes 1-2 from an LDS table, the digit bias folded differently).
+#ifndef FHESTR_SWAP11
+#define FHESTR_SWAP11 0
+#endif
 template <int LOGN, int LOGR, int K1, int L>
 struct BrWideCfg {
     static constexpr int N = 1 << LOGN;
     static constexpr int P = N / 2;
-    using PL = typename PlanFor<LOGN - 1, LOGR>::type;
+    // N = 4096 with four points per thread runs FftSwap11 (round 4); the wide kernel is the only one for that size, so its
+    // Fourier key is simply in that plan's order (bsk_convert_wide_kernel)
+    static constexpr bool OWN_PLAN = FHESTR_SWAP11 && LOGN == 12 && LOGR == 2;
+    using PL = typename std::conditional<OWN_PLAN, FftSwap11, typename PlanFor<LOGN - 1, LOGR>::type>::type;
     static constexpr int R = PL::R;
     static constexpr int T = PL::T;
     static constexpr int THREADS = T;
@@ -876,6 +886,41 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
                     else out[(size_t)p * N + (N - j)] = 0 - v;
                 }
             }
+}
+
+// Standard-domain polynomials -> the wide kernel's Fourier layout when that kernel has a plan of its own (BrWideCfg::OWN_PLAN).
+// One polynomial per workgroup; the arithmetic of bsk_convert_kernel.
+template <int LOGN, int LOGR, int K1, int L>
+__global__ void __launch_bounds__((BrWideCfg<LOGN, LOGR, K1, L>::THREADS))
+bsk_convert_wide_kernel(const uint64_t* __restrict__ bsk_std, double* __restrict__ fbsk, uint32_t n_polys) {
+    using CFG = BrWideCfg<LOGN, LOGR, K1, L>;
+    using PL = typename CFG::PL;
+    constexpr int N = CFG::N, P = CFG::P, R = CFG::R, T = CFG::T;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* planes = reinterpret_cast<double*>(smem);
+    const int tau = threadIdx.x;
+    const uint32_t poly = blockIdx.x;
+    if (poly >= n_polys) return;             // whole workgroup
+    FftConsts<PL> fc;
+    fft_init_consts<PL>(fc, tau);
+    cplx x[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        const int j = PL::point(tau, m);
+        const uint64_t a = bsk_std[(size_t)poly * N + j];
+        const uint64_t b = bsk_std[(size_t)poly * N + j + P];
+        cplx z;
+        z.re = i64_to_f64(a) * (5.421010862427522e-20 / P);
+        z.im = i64_to_f64(b) * (5.421010862427522e-20 / P);
+        double sn, cs;
+        sincospi((double)j / (double)N, &sn, &cs);
+        cplx w; w.re = cs; w.im = sn;
+        x[m] = cmul(z, w);
+    }
+    fft_forward<PL>(x, fc, planes, planes + CFG::PLANE, tau);
+    double2* out = reinterpret_cast<double2*>(fbsk) + (size_t)poly * P;
+#pragma unroll
+    for (int rho = 0; rho < R; rho++) out[rho * T + tau] = make_double2(x[rho].re, x[rho].im);
 }
 
 }  // namespace fhe
