@@ -748,6 +748,54 @@ __device__ __forceinline__ void swap9_inverse(cplx* x, const FftConsts<FftSwap9>
     swap9_inverse_tail(x, c, re, im, tau);
 }
 
+// Swap-plan constants with the twiddles of passes 1 and 2 in an LDS table (few distinct values: tp < S/4) and fetched into
+// registers just before the stage that multiplies by them; pass 0's stay in VGPRs, pass 3's are wave-uniform (scalar).  For the
+// kernels whose register file is full without them (N = 4096: 36 VGPRs of loop-invariant twiddles were what spilled).
+// Table: [s = 1][q - 1][tp < S1 / 4], then [s = 2][q - 1][tp < S2 / 4].
+template <class PL>
+struct FftSwapLdsConsts {
+    static constexpr int N1 = 1 << (PL::log_S(1) - 2), N2 = 1 << (PL::log_S(2) - 2);
+    static constexpr int ENTRIES = 3 * N1 + 3 * N2;
+    mutable cplx tw[4][4];
+    const double2* table;
+    int tp1, tp2;
+    __device__ __forceinline__ static void fill(double2* b, int tid, int nthreads) {
+        for (int e = tid; e < ENTRIES; e += nthreads) {
+            const bool second = e >= 3 * N1;
+            const int i = second ? e - 3 * N1 : e, n = second ? N2 : N1, lS = second ? PL::log_S(2) : PL::log_S(1);
+            const int q = i / n + 1, tp = i % n;
+            double sn, cs;
+            sincospi(-2.0 * (double)(q * tp) / (double)(1 << lS), &sn, &cs);
+            b[e] = make_double2(cs, sn);
+        }
+    }
+    __device__ __forceinline__ void init(const double2* t, int tau) {
+        table = t;
+        const int lane = tau & 63, w = tau >> 6;
+        tp1 = ((lane & 15) << PL::LOGW) | w;
+        tp2 = ((lane >> 4) << PL::LOGW) | w;
+        const int tp0 = (lane << PL::LOGW) | w, ws = __builtin_amdgcn_readfirstlane(w);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            double sn, cs;
+            sincospi(-2.0 * (double)(q * tp0) / (double)(1 << PL::log_S(0)), &sn, &cs);
+            tw[0][q].re = cs; tw[0][q].im = sn;
+            sincospi(-2.0 * (double)(q * ws) / (double)(1 << PL::log_S(3)), &sn, &cs);
+            tw[3][q].re = cs; tw[3][q].im = sn;
+        }
+    }
+    __device__ __forceinline__ cplx get(int s, int q) const { return tw[s][q]; }      // (generic code paths never taken by swap plans)
+    __device__ __forceinline__ void load(int s) const {          // s = 1 or 2
+#pragma unroll
+        for (int q = 1; q < 4; q++) {
+            const double2 v = s == 1 ? table[(q - 1) * N1 + tp1] : table[3 * N1 + (q - 1) * N2 + tp2];
+            tw[s][q].re = v.x; tw[s][q].im = v.y;
+        }
+    }
+};
+template <class PL> __device__ __forceinline__ void swap_load_tw(const FftConsts<PL>&, int) {}
+template <class PL> __device__ __forceinline__ void swap_load_tw(const FftSwapLdsConsts<PL>& c, int s) { c.load(s); }
+
 // ---- FftSwap11 (2048 points, eight waves) ------------------------------------------------------------------------
 __device__ __forceinline__ void swap11_forward_tail(cplx* x, const double* re, const double* im, int tau) {
     const int lane = tau & 63, w = __builtin_amdgcn_readfirstlane(tau >> 6), r = w >> 1;
@@ -800,11 +848,13 @@ __device__ __forceinline__ void swap11_inverse_gather(cplx* x, const double* re,
         x[r].im = fma(sg, im[b], im[a]);
     }
 }
-template <int NPOLY>
-__device__ __forceinline__ void swap11_forward(cplx (*x)[4], const FftConsts<FftSwap11>& c, double* re0, int poly_stride, int im_off, int tau) {
+template <int NPOLY, class C>
+__device__ __forceinline__ void swap11_forward(cplx (*x)[4], const C& c, double* re0, int poly_stride, int im_off, int tau) {
+    swap_load_tw(c, 1);
 #pragma unroll
     for (int p = 0; p < NPOLY; p++) swap10_fwd_stage1(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
     wave_local_fence();
+    swap_load_tw(c, 2);
 #pragma unroll
     for (int p = 0; p < NPOLY; p++) swap10_fwd_stage2(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
     wave_local_fence();
@@ -818,8 +868,8 @@ __device__ __forceinline__ void swap11_forward(cplx (*x)[4], const FftConsts<Fft
     }
     __syncthreads();             // rows are shared by pairs of waves: nobody stores into them before everybody has read
 }
-template <int NPOLY>
-__device__ __forceinline__ void swap11_inverse(cplx (*x)[4], const FftConsts<FftSwap11>& c, double* re0, int poly_stride, int im_off, int tau) {
+template <int NPOLY, class C>
+__device__ __forceinline__ void swap11_inverse(cplx (*x)[4], const C& c, double* re0, int poly_stride, int im_off, int tau) {
 #pragma unroll
     for (int p = 0; p < NPOLY; p++) {
         swap11_inverse_head(x[p], re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
@@ -829,12 +879,14 @@ __device__ __forceinline__ void swap11_inverse(cplx (*x)[4], const FftConsts<Fft
 #pragma unroll
     for (int p = 0; p < NPOLY; p++) swap11_inverse_gather(x[p], re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
     __syncthreads();             // the wave-local exchange below stores into rows other waves have just read
+    swap_load_tw(c, 2);
 #pragma unroll
     for (int p = 0; p < NPOLY; p++) swap10_inv_stage1_compute(x[p], c);
     wave_local_fence();
 #pragma unroll
     for (int p = 0; p < NPOLY; p++) swap10_inv_stage2(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
     wave_local_fence();
+    swap_load_tw(c, 1);
 #pragma unroll
     for (int p = 0; p < NPOLY; p++) swap10_inv_stage3(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
 }

@@ -618,12 +618,12 @@ blind_rotate_kernel(BlindRotateArgs args) {
 // k+1 independent FFT streams to overlap LDS round trips with butterflies, and the smaller
 // footprint (accumulator copy + exchange planes) lets two LWEs share a CU for batches >= 512.
 // Barriers per CMUX step: forward exchange 0->1, inverse exchange 1->0, accumulator publish.
-// FftSwap11 for N = 4096 (negacyclic_fft.hip.h): correct (decrypt and oracle-phase tests of the five N = 4096 sets pass with it)
-// and 60 % fewer LDS stores, but as compiled today its twiddles push the wide kernel to 51 / 69 spilled registers whose
-// reloads queue behind the prefetched key rows: 11.9 ms per 256 LWEs against 7.55 on the generic plan (profiles/r04_n4096.txt).
-// Off until the register budget is sorted out (twiddles of passes 1-2 from an LDS table, the digit bias folded differently).
+// FftSwap11 for N = 4096 (negacyclic_fft.hip.h; -DFHESTR_SWAP11=0: the generic plan).  60 % fewer LDS stores; its twiddles of
+// passes 1-2 come from an LDS table (FftSwapLdsConsts) and the digit bias is subtracted as an integer, because with everything in
+// VGPRs next to the prefetched key rows the kernel spilled 51 registers whose reloads queue behind the key loads (11.9 ms per
+// 256 LWEs against the generic plan's 7.55; now 6.8: profiles/r04_n4096.txt).
 #ifndef FHESTR_SWAP11
-#define FHESTR_SWAP11 0
+#define FHESTR_SWAP11 1
 #endif
 template <int LOGN, int LOGR, int K1, int L>
 struct BrWideCfg {
@@ -640,7 +640,8 @@ struct BrWideCfg {
     static constexpr int GROUP_SLOTS = 2 * P + 4;
     // plans with more than four passes keep only pass 0's twiddles in VGPRs (FftHybridConsts)
     static constexpr bool TW_IN_LDS = !PL::SWAP && PL::NTW > 4;
-    static constexpr size_t LDS_TW = TW_IN_LDS ? (size_t)FftHybridConsts<PL>::ENTRIES * 16 : 0;
+    static constexpr size_t LDS_TW = TW_IN_LDS ? (size_t)FftHybridConsts<PL>::ENTRIES * 16
+                                     : OWN_PLAN ? (size_t)FftSwapLdsConsts<PL>::ENTRIES * 16 : 0;
     static constexpr size_t LDS_FIXED = (size_t)K1 * N * 8 /*acc*/ + (size_t)K1 * GROUP_SLOTS * 8 /*x*/ + LDS_TW;
     // N >= 4096: the accumulator lives in its LDS copy only -- a thread re-reads its own 2 K1 R coefficients at the gather and
     // at the update (the dense kernel's arrangement, pbs_dense_kernels.hip.h) instead of holding them in 4 K1 R VGPRs next to
@@ -693,8 +694,12 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
         lds_d[i] = a == 0 ? 0xFFFFFFFFu : modulus_switch(a, LOGN);
     }
 
-    typename std::conditional<CFG::TW_IN_LDS, FftHybridConsts<PL>, FftConsts<PL>>::type fc;
-    if constexpr (CFG::TW_IN_LDS) {
+    typename std::conditional<CFG::OWN_PLAN, FftSwapLdsConsts<PL>,
+                              typename std::conditional<CFG::TW_IN_LDS, FftHybridConsts<PL>, FftConsts<PL>>::type>::type fc;
+    if constexpr (CFG::OWN_PLAN) {
+        FftSwapLdsConsts<PL>::fill(lds_tw, threadIdx.x, CFG::THREADS);     // visible after the barrier below
+        fc.init(lds_tw, tau);
+    } else if constexpr (CFG::TW_IN_LDS) {
         FftHybridConsts<PL>::fill(lds_tw, threadIdx.x, CFG::THREADS);      // visible after the barrier below
         fc.init(lds_tw, tau);
     } else {
@@ -813,7 +818,18 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
             for (int p = 0; p < K1; p++)
 #pragma unroll
                 for (int m = 0; m < R; m++) {
-                    if (L == 1) { x[p][m] = digit_point(st_lo[p][m], st_hi[p][m], twist[m], twbias[m]); continue; }
+                    if (L == 1) {
+                        if constexpr (CFG::OWN_PLAN) {       // no register for the folded bias: subtract it as an integer first
+                            const int32_t cbi = (int32_t)((1u << (args.base_log * L - 1)) - 1u);
+                            cplx z;
+                            z.re = (double)((int32_t)st_lo[p][m] - cbi);
+                            z.im = (double)((int32_t)st_hi[p][m] - cbi);
+                            x[p][m] = cmul(z, twist[m]);
+                        } else {
+                            x[p][m] = digit_point(st_lo[p][m], st_hi[p][m], twist[m], twbias[m]);
+                        }
+                        continue;
+                    }
                     cplx z;
                     z.re = (double)decomp_next_digit(st_lo[p][m], args.base_log);
                     z.im = (double)decomp_next_digit(st_hi[p][m], args.base_log);
