@@ -59,6 +59,8 @@ struct BrVariant {
     const void* rotate_fn;
     const void* convert_fn;
     bool convert_one_per_block = false;   // the conversion kernel takes one polynomial per workgroup (K1 otherwise)
+    bool own_plan = false;                // wide layout on a plan of its own: when it is not the engine's primary variant it reads the
+                                          // dense kernel's copy of the key (same plan), not the primary variant's
     // multi-bit, small batches: build every (LWE, group) GGSW on the whole GPU first, then rotate against them
     const void* combine_fn = nullptr;
     const void* rotate_combined_fn = nullptr;
@@ -108,11 +110,12 @@ BrVariant make_wide_variant() {
     v.threads = CFG::THREADS;
     v.lds_bytes = CFG::LDS_FIXED;
     v.rotate_fn = reinterpret_cast<const void*>(&blind_rotate_wide_kernel<LOGN, LOGR, K1, L>);
-    if constexpr (CFG::OWN_PLAN) {        // N = 4096: FftSwap11 -- the key in that plan's order, one polynomial per workgroup
+    if constexpr (CFG::OWN_PLAN) {        // FftSwap11 / FftSwap9: the key in that plan's order, one polynomial per workgroup
         v.convert_fn = reinterpret_cast<const void*>(&bsk_convert_wide_kernel<LOGN, LOGR, K1, L>);
         v.convert_threads = CFG::THREADS;
         v.convert_lds = (size_t)CFG::GROUP_SLOTS * 8;
         v.convert_one_per_block = true;
+        v.own_plan = true;
     }
     if constexpr (LOGN == 10 && LOGR == 2 && K1 == 3 && L == 1) {       // N = 1024, k = 2 (pbs_dense_kernels.hip.h)
         using DC = BrDenseCfg<LOGN, K1>;
@@ -655,7 +658,7 @@ int Engine::install_keys(uint64_t* d_ksk_std, uint64_t* d_std) {
     HIP_TRY(hipMalloc((void**)&d_fbsk, bsk_len * 8));   // N u64 -> N/2 c64: same byte count
     if (convert_polys(d_std, d_fbsk, (uint32_t)(bsk_len / p.N))) return 1;
     if (d_fbsk_dense) { HIP_TRY(hipFree(d_fbsk_dense)); d_fbsk_dense = nullptr; }
-    if (variant_large->dense_convert_fn) {      // the dense kernel's own copy of the key (N = 1024, k = 2: 54.7 MB)
+    if (variant_large->dense_convert_fn) {      // the copy of the key in FftSwap9's order (N = 1024, k = 2: 54.7 MB): dense and wide kernels
         HIP_TRY(hipMalloc((void**)&d_fbsk_dense, bsk_len * 8));
         uint32_t n_polys = (uint32_t)(bsk_len / p.N);
         void* cargs[] = {(void*)&d_std, (void*)&d_fbsk_dense, (void*)&n_polys};
@@ -815,6 +818,10 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
     if (two_per_cu) {          // overlapped throughput mode: the compact layout whatever the batch size, on the given stream
         const BrVariant* w = variant_large;
         a.fair_shift = wide_fair_shift;      // the two launches that share the GPU progress at the same rate (110 k -> 122 k PBS/s)
+        if (w->own_plan && w != variant) {
+            if (!d_fbsk_dense) return fail("wide kernel: the key copy in its plan's order is missing");
+            a.fbsk = d_fbsk_dense;
+        }
         HIP_TRY(hipLaunchKernel(w->rotate_fn, dim3(count), dim3(w->threads), args, w->lds_bytes + (size_t)p.n * w->lds_per_n, on ? on : stream));
         return 0;
     }
@@ -957,6 +964,10 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
     }
     uint32_t grid = count;
     if (keep_busy && !v->wide && !v->large && count * 2 <= (uint32_t)cu_count) grid = count * ((uint32_t)cu_count / count);
+    if (v->own_plan && v != variant) {
+        if (!d_fbsk_dense) return fail("wide kernel: the key copy in its plan's order is missing");
+        a.fbsk = d_fbsk_dense;
+    }
     HIP_TRY(hipLaunchKernel(v->rotate_fn, dim3(grid), dim3(v->threads), args,
                             v->lds_bytes + (size_t)p.n * v->lds_per_n, stream));
     return 0;

@@ -733,6 +733,36 @@ __device__ __forceinline__ void swap9_inverse_tail(cplx* x, const C& c, double* 
     wave_local_fence();
     swap10_inv_stage3(x, c, re, im, tau);
 }
+// NPOLY polynomials carried by the same threads, stage by stage (one polynomial's LDS round trip behind the others' butterflies)
+template <int NPOLY>
+__device__ __forceinline__ void swap9_forward_multi(cplx (*x)[4], const FftConsts<FftSwap9>& c, double* re0, int poly_stride, int im_off, int tau) {
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap10_fwd_stage1(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    wave_local_fence();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap10_fwd_stage2(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    wave_local_fence();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap10_fwd_stage3(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap9_forward_tail(x[p], re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    __syncthreads();             // the other wave reads this wave's rows in its tail: nobody stores into them before both have read
+}
+template <int NPOLY>
+__device__ __forceinline__ void swap9_inverse_multi(cplx (*x)[4], const FftConsts<FftSwap9>& c, double* re0, int poly_stride, int im_off, int tau) {
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap9_inverse_head(x[p], re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap10_inv_stage1(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    wave_local_fence();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap10_inv_stage2(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+    wave_local_fence();
+#pragma unroll
+    for (int p = 0; p < NPOLY; p++) swap10_inv_stage3(x[p], c, re0 + p * poly_stride, re0 + p * poly_stride + im_off, tau);
+}
 __device__ __forceinline__ void swap9_forward(cplx* x, const FftConsts<FftSwap9>& c, double* re, double* im, int tau) {
     swap10_fwd_stage1(x, c, re, im, tau);
     wave_local_fence();
@@ -1088,9 +1118,11 @@ __device__ __forceinline__ bool pass_sync_is_wave_local(int log_S_next) { return
 template <class PL, int NPOLY, class C>
 __device__ __forceinline__ void fft_forward_multi(cplx (*x)[PL::R], const C& c, double* re0,
                                                   int poly_stride, int im_off, int tau) {
-    static_assert(!PL::SWAP || PL::LOGP == 10 || PL::LOGP == 11, "several polynomials per thread: FftSwap10 / FftSwap11");
     if constexpr (PL::SWAP && PL::LOGP == 11) {
         swap11_forward<NPOLY>(x, c, re0, poly_stride, im_off, tau);
+        return;
+    } else if constexpr (PL::SWAP && PL::LOGP == 9) {
+        swap9_forward_multi<NPOLY>(x, c, re0, poly_stride, im_off, tau);
         return;
     } else if constexpr (PL::SWAP) {
         swap10_forward<NPOLY>(x, c, re0, poly_stride, im_off, tau);
@@ -1124,9 +1156,11 @@ __device__ __forceinline__ void fft_forward_multi(cplx (*x)[PL::R], const C& c, 
 template <class PL, int NPOLY, class C>
 __device__ __forceinline__ void fft_inverse_multi(cplx (*x)[PL::R], const C& c, double* re0,
                                                   int poly_stride, int im_off, int tau) {
-    static_assert(!PL::SWAP || PL::LOGP == 10 || PL::LOGP == 11, "several polynomials per thread: FftSwap10 / FftSwap11");
     if constexpr (PL::SWAP && PL::LOGP == 11) {
         swap11_inverse<NPOLY>(x, c, re0, poly_stride, im_off, tau);
+        return;
+    } else if constexpr (PL::SWAP && PL::LOGP == 9) {
+        swap9_inverse_multi<NPOLY>(x, c, re0, poly_stride, im_off, tau);
         return;
     } else if constexpr (PL::SWAP) {
         swap10_inverse<NPOLY>(x, c, re0, poly_stride, im_off, tau);

@@ -625,14 +625,24 @@ blind_rotate_kernel(BlindRotateArgs args) {
 #ifndef FHESTR_SWAP11
 #define FHESTR_SWAP11 1
 #endif
+// FftSwap9 under the N = 1024 two-per-CU kernel as well (three polynomials stage by stage, the dense kernel's key copy): correct
+// (tests, 87 k-PBS soak) but 10.0 instead of 4.95 ms per 512 LWEs -- two thirds of the wave-cycles wait at the workgroup
+// barriers (SQ_WAIT_ANY 67 %, waits on instructions 4 %), not understood yet; off (profiles/r04_n1024.txt).
+#ifndef FHESTR_WIDE_SWAP9
+#define FHESTR_WIDE_SWAP9 0
+#endif
 template <int LOGN, int LOGR, int K1, int L>
 struct BrWideCfg {
     static constexpr int N = 1 << LOGN;
     static constexpr int P = N / 2;
     // N = 4096 with four points per thread runs FftSwap11 (round 4); the wide kernel is the only one for that size, so its
     // Fourier key is simply in that plan's order (bsk_convert_wide_kernel)
-    static constexpr bool OWN_PLAN = FHESTR_SWAP11 && LOGN == 12 && LOGR == 2;
-    using PL = typename std::conditional<OWN_PLAN, FftSwap11, typename PlanFor<LOGN - 1, LOGR>::type>::type;
+    // N = 1024 with four points per thread (k = 2: PARAM_MESSAGE_2_CARRY_1 ...) runs FftSwap9 and reads the key copy the dense
+    // kernel reads (same plan, same order) -- the one-per-CU kernel of that size keeps the generic plan and its own copy
+    static constexpr bool OWN_PLAN = (FHESTR_SWAP11 && LOGN == 12 && LOGR == 2) || (FHESTR_WIDE_SWAP9 && LOGN == 10 && LOGR == 2);
+    static constexpr bool LDS_TWIDDLES = OWN_PLAN && LOGN == 12;        // FftSwapLdsConsts: where the register file is full
+    using PL = typename std::conditional<!OWN_PLAN, typename PlanFor<LOGN - 1, LOGR>::type,
+                                         typename std::conditional<LOGN == 12, FftSwap11, FftSwap9>::type>::type;
     static constexpr int R = PL::R;
     static constexpr int T = PL::T;
     static constexpr int THREADS = T;
@@ -641,7 +651,7 @@ struct BrWideCfg {
     // plans with more than four passes keep only pass 0's twiddles in VGPRs (FftHybridConsts)
     static constexpr bool TW_IN_LDS = !PL::SWAP && PL::NTW > 4;
     static constexpr size_t LDS_TW = TW_IN_LDS ? (size_t)FftHybridConsts<PL>::ENTRIES * 16
-                                     : OWN_PLAN ? (size_t)FftSwapLdsConsts<PL>::ENTRIES * 16 : 0;
+                                     : LDS_TWIDDLES ? (size_t)FftSwapLdsConsts<PL>::ENTRIES * 16 : 0;
     static constexpr size_t LDS_FIXED = (size_t)K1 * N * 8 /*acc*/ + (size_t)K1 * GROUP_SLOTS * 8 /*x*/ + LDS_TW;
     // N >= 4096: the accumulator lives in its LDS copy only -- a thread re-reads its own 2 K1 R coefficients at the gather and
     // at the update (the dense kernel's arrangement, pbs_dense_kernels.hip.h) instead of holding them in 4 K1 R VGPRs next to
@@ -694,9 +704,9 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
         lds_d[i] = a == 0 ? 0xFFFFFFFFu : modulus_switch(a, LOGN);
     }
 
-    typename std::conditional<CFG::OWN_PLAN, FftSwapLdsConsts<PL>,
+    typename std::conditional<CFG::LDS_TWIDDLES, FftSwapLdsConsts<PL>,
                               typename std::conditional<CFG::TW_IN_LDS, FftHybridConsts<PL>, FftConsts<PL>>::type>::type fc;
-    if constexpr (CFG::OWN_PLAN) {
+    if constexpr (CFG::LDS_TWIDDLES) {
         FftSwapLdsConsts<PL>::fill(lds_tw, threadIdx.x, CFG::THREADS);     // visible after the barrier below
         fc.init(lds_tw, tau);
     } else if constexpr (CFG::TW_IN_LDS) {
@@ -819,7 +829,7 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
 #pragma unroll
                 for (int m = 0; m < R; m++) {
                     if (L == 1) {
-                        if constexpr (CFG::OWN_PLAN) {       // no register for the folded bias: subtract it as an integer first
+                        if constexpr (CFG::LDS_TWIDDLES) {       // no register for the folded bias: subtract it as an integer first
                             const int32_t cbi = (int32_t)((1u << (args.base_log * L - 1)) - 1u);
                             cplx z;
                             z.re = (double)((int32_t)st_lo[p][m] - cbi);
