@@ -626,8 +626,9 @@ blind_rotate_kernel(BlindRotateArgs args) {
 #define FHESTR_SWAP11 1
 #endif
 // FftSwap9 under the N = 1024 two-per-CU kernel as well (three polynomials stage by stage, the dense kernel's key copy): correct
-// (tests, 87 k-PBS soak) but 10.0 instead of 4.95 ms per 512 LWEs -- two thirds of the wave-cycles wait at the workgroup
-// barriers (SQ_WAIT_ANY 67 %, waits on instructions 4 %), not understood yet; off (profiles/r04_n1024.txt).
+// (tests, 87 k-PBS soak); with its key loads batched per GGSW row (ROW_BATCH: left alone the compiler serialised them, 10.0 ms per
+// 512 LWEs) it is level with the generic plan, which then took the whole-key prefetch below and is the faster of the two in
+// the overlapped mode; off (profiles/r04_n1024.txt).
 #ifndef FHESTR_WIDE_SWAP9
 #define FHESTR_WIDE_SWAP9 0
 #endif
@@ -662,7 +663,13 @@ struct BrWideCfg {
     static constexpr bool ACC_IN_LDS = LOGN >= FHESTR_WIDE_ACC_LDS_LOGN;
     // keep the whole Fourier GGSW of a step in VGPRs only when it is small
     // (also where the twiddles moved to LDS: without the prefetch N = 4096 has no spills but runs 9.5 instead of 7.8 ms)
-    static constexpr bool PREFETCH_ALL = K1 * K1 * R * 4 <= 64;
+    // ... or where the kernel runs one wave per SIMD anyway (N = 1024 with k = 2: three polynomials per thread, 270-300 VGPRs):
+    // 144 more registers cost no occupancy there and hide the key's L2 latency behind the forward transforms
+#ifndef FHESTR_WIDE_K3_PREFETCH
+#define FHESTR_WIDE_K3_PREFETCH 1
+#endif
+    static constexpr bool PREFETCH_ALL = K1 * K1 * R * 4 <= 64 || (FHESTR_WIDE_K3_PREFETCH && LOGN == 10 && LOGR == 2 && K1 == 3 && L == 1);
+    static constexpr bool ROW_BATCH = !PREFETCH_ALL && OWN_PLAN && L == 1;      // see the products in the kernel
 };
 
 template <int LOGN, int LOGR, int K1, int L>
@@ -848,12 +855,26 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
             fft_forward_multi<PL, K1>(x, fc, lds_x, CFG::GROUP_SLOTS, CFG::PLANE, tau);
             const double2* bk = bk0 + (size_t)lvl_idx * K1 * K1 * P;
 #pragma unroll
-            for (int row = 0; row < K1; row++)
+            for (int row = 0; row < K1; row++) {
+                // FftSwap9 build of this kernel (three polynomials, no key prefetch): a GGSW row is requested as one batch of
+                // K1 R loads and only then multiplied -- left to itself the compiler emitted load, s_waitcnt vmcnt(0), four
+                // FMAs, 36 times per step (10.0 instead of 4.95 ms per 512 LWEs, profiles/r04_n1024.txt)
+                double2 krow[CFG::ROW_BATCH ? K1 : 1][CFG::ROW_BATCH ? R : 1];
+                if constexpr (CFG::ROW_BATCH) {
+#pragma unroll
+                    for (int col = 0; col < K1; col++)
+#pragma unroll
+                        for (int rho = 0; rho < R; rho++)
+                            krow[col][rho] = key_load(key_rsrc, key_off,
+                                (uint32_t)((i * GGSW_ELEMS + (size_t)lvl_idx * K1 * K1 * P + ((size_t)row * K1 + col) * P + rho * T) * 16));
+                    FHE_PIN_ORDER();
+                }
 #pragma unroll
                 for (int col = 0; col < K1; col++)
 #pragma unroll
                     for (int rho = 0; rho < R; rho++) {
-                        const double2 bv = (CFG::PREFETCH_ALL && it == 0)
+                        const double2 bv = CFG::ROW_BATCH ? krow[CFG::ROW_BATCH ? col : 0][CFG::ROW_BATCH ? rho : 0]
+                                           : (CFG::PREFETCH_ALL && it == 0)
                                                ? bpre[CFG::PREFETCH_ALL ? row : 0][CFG::PREFETCH_ALL ? col : 0][rho]
                                                : bk[((size_t)row * K1 + col) * P + rho * T + tau];
                         const cplx f = x[row][rho];
@@ -865,6 +886,7 @@ blind_rotate_wide_kernel(BlindRotateArgs args) {
                             outf[col][rho].im = fma(bv.x, f.im, fma(bv.y, f.re, outf[col][rho].im));
                         }
                     }
+            }
             if (it + 1 < L) __syncthreads();   // next level's pass-0 writes vs this level's last reads
         }
 
