@@ -59,6 +59,7 @@ struct BrVariant {
     const void* rotate_fn;
     const void* convert_fn;
     bool convert_one_per_block = false;   // the conversion kernel takes one polynomial per workgroup (K1 otherwise)
+    const void* rotate_keypf_fn = nullptr; // wide layout with the whole key of a step prefetched (single launches only, see BrWideCfg)
     bool own_plan = false;                // wide layout on a plan of its own: when it is not the engine's primary variant it reads the
                                           // dense kernel's copy of the key (same plan), not the primary variant's
     // multi-bit, small batches: build every (LWE, group) GGSW on the whole GPU first, then rotate against them
@@ -117,6 +118,8 @@ BrVariant make_wide_variant() {
         v.convert_one_per_block = true;
         v.own_plan = true;
     }
+    if constexpr (LOGN == 10 && LOGR == 2 && K1 == 3 && L == 1)         // N = 1024, k = 2: single launches of 257 ... 512 LWEs
+        v.rotate_keypf_fn = reinterpret_cast<const void*>(&blind_rotate_wide_kernel<LOGN, LOGR, K1, L, true>);
     if constexpr (LOGN == 10 && LOGR == 2 && K1 == 3 && L == 1) {       // N = 1024, k = 2 (pbs_dense_kernels.hip.h)
         using DC = BrDenseCfg<LOGN, K1>;
         static_assert(DC::THREADS == CFG::THREADS, "same launch shape as the wide kernel");
@@ -968,7 +971,7 @@ int Engine::launch_blind_rotate(const uint64_t* d_sm, const uint32_t* d_lut_idx,
         if (!d_fbsk_dense) return fail("wide kernel: the key copy in its plan's order is missing");
         a.fbsk = d_fbsk_dense;
     }
-    HIP_TRY(hipLaunchKernel(v->rotate_fn, dim3(grid), dim3(v->threads), args,
+    HIP_TRY(hipLaunchKernel(v->rotate_keypf_fn && v->wide ? v->rotate_keypf_fn : v->rotate_fn, dim3(grid), dim3(v->threads), args,
                             v->lds_bytes + (size_t)p.n * v->lds_per_n, stream));
     return 0;
 }

@@ -632,7 +632,7 @@ blind_rotate_kernel(BlindRotateArgs args) {
 #ifndef FHESTR_WIDE_SWAP9
 #define FHESTR_WIDE_SWAP9 0
 #endif
-template <int LOGN, int LOGR, int K1, int L>
+template <int LOGN, int LOGR, int K1, int L, bool KEYPF = false>
 struct BrWideCfg {
     static constexpr int N = 1 << LOGN;
     static constexpr int P = N / 2;
@@ -663,19 +663,19 @@ struct BrWideCfg {
     static constexpr bool ACC_IN_LDS = LOGN >= FHESTR_WIDE_ACC_LDS_LOGN;
     // keep the whole Fourier GGSW of a step in VGPRs only when it is small
     // (also where the twiddles moved to LDS: without the prefetch N = 4096 has no spills but runs 9.5 instead of 7.8 ms)
-    // ... or where the kernel runs one wave per SIMD anyway (N = 1024 with k = 2: three polynomials per thread, 270-300 VGPRs):
-    // 144 more registers cost no occupancy there and hide the key's L2 latency behind the forward transforms
-#ifndef FHESTR_WIDE_K3_PREFETCH
-#define FHESTR_WIDE_K3_PREFETCH 1
-#endif
-    static constexpr bool PREFETCH_ALL = K1 * K1 * R * 4 <= 64 || (FHESTR_WIDE_K3_PREFETCH && LOGN == 10 && LOGR == 2 && K1 == 3 && L == 1);
+    // ... or, KEYPF, where the kernel runs one wave per SIMD anyway (N = 1024 with k = 2: three polynomials per thread, 270-300
+    // VGPRs): 144 more registers cost no occupancy there and hide the key's L2 latency behind the forward transforms (512 LWEs
+    // 4.95 -> 4.6-4.8 ms).  A second instantiation, for single launches only: two launches of it overlapped on two streams
+    // (pipeline mode 2) mostly fail to co-reside (4.15 ms per 256-LWE call in 5 runs of 6, 2.27 in the sixth; the 272-register
+    // build: 2.47-2.61 every time) -- profiles/r04_n1024.txt.
+    static constexpr bool PREFETCH_ALL = K1 * K1 * R * 4 <= 64 || KEYPF;
     static constexpr bool ROW_BATCH = !PREFETCH_ALL && OWN_PLAN && L == 1;      // see the products in the kernel
 };
 
-template <int LOGN, int LOGR, int K1, int L>
-__global__ void __launch_bounds__((BrWideCfg<LOGN, LOGR, K1, L>::THREADS))
+template <int LOGN, int LOGR, int K1, int L, bool KEYPF = false>
+__global__ void __launch_bounds__((BrWideCfg<LOGN, LOGR, K1, L, KEYPF>::THREADS))
 blind_rotate_wide_kernel(BlindRotateArgs args) {
-    using CFG = BrWideCfg<LOGN, LOGR, K1, L>;
+    using CFG = BrWideCfg<LOGN, LOGR, K1, L, KEYPF>;
     using PL = typename CFG::PL;
     constexpr int N = CFG::N, P = CFG::P, R = CFG::R, T = CFG::T;
     extern __shared__ __align__(16) unsigned char smem[];
